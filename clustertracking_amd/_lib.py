@@ -1,0 +1,167 @@
+"""ctypes binding of ``libctrefine.so`` (the HIP engine, C-ABI ``include/ctrefine.h``).
+
+There is no CPU fallback: if the library is missing, or no MI355X is visible,
+the calls raise.
+"""
+import ctypes as C
+import os
+import threading
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libctrefine.so')
+
+# every symbol include/ctrefine.h declares
+EXPORTS = ('ctr_abi_version', 'ctr_create', 'ctr_destroy', 'ctr_last_error',
+           'ctr_validate_problem', 'ctr_cluster_n_vars', 'ctr_refine_batch',
+           'ctr_plan_create', 'ctr_plan_destroy', 'ctr_refine_batch_device',
+           'ctr_frame_max_device', 'ctr_synchronize', 'ctr_last_kernel_ms')
+
+_lib = None
+_lock = threading.Lock()
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raises EngineError when it is absent."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(
+                "HIP engine not built: %s is missing. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C clustertracking_amd/csrc`. There is no CPU fallback."
+                % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        P = C.POINTER
+        lib.ctr_abi_version.restype = C.c_int
+        lib.ctr_create.argtypes = [P(C.c_void_p), C.c_int]
+        lib.ctr_create.restype = C.c_int
+        lib.ctr_destroy.argtypes = [C.c_void_p]
+        lib.ctr_destroy.restype = None
+        lib.ctr_last_error.argtypes = [C.c_void_p]
+        lib.ctr_last_error.restype = C.c_char_p
+        lib.ctr_validate_problem.argtypes = [P(_abi.Problem), C.c_char_p, C.c_int]
+        lib.ctr_validate_problem.restype = C.c_int
+        lib.ctr_cluster_n_vars.argtypes = [P(_abi.Problem), C.c_int]
+        lib.ctr_cluster_n_vars.restype = C.c_int
+        lib.ctr_refine_batch.argtypes = [C.c_void_p, P(_abi.Problem), P(_abi.Batch)]
+        lib.ctr_refine_batch.restype = C.c_int
+        lib.ctr_plan_create.argtypes = [C.c_void_p, P(_abi.Problem), C.c_int64,
+                                        C.c_void_p, P(C.c_void_p)]
+        lib.ctr_plan_create.restype = C.c_int
+        lib.ctr_plan_destroy.argtypes = [C.c_void_p]
+        lib.ctr_plan_destroy.restype = None
+        lib.ctr_refine_batch_device.argtypes = [C.c_void_p, C.c_void_p,
+                                                P(_abi.Batch), C.c_void_p]
+        lib.ctr_refine_batch_device.restype = C.c_int
+        lib.ctr_frame_max_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32,
+                                             C.c_int64, C.c_int64, C.c_void_p,
+                                             C.c_void_p]
+        lib.ctr_frame_max_device.restype = C.c_int
+        lib.ctr_synchronize.argtypes = [C.c_void_p, C.c_void_p]
+        lib.ctr_synchronize.restype = C.c_int
+        lib.ctr_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_double), P(C.c_double)]
+        lib.ctr_last_kernel_ms.restype = C.c_int
+        if lib.ctr_abi_version() != _abi.ABI_VERSION:
+            raise EngineError("libctrefine.so ABI version mismatch")
+        _lib = lib
+        return lib
+
+
+class Engine(object):
+    """One engine handle bound to one GPU (``ctr_create`` / ``ctr_destroy``)."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        rc = self._lib.ctr_create(C.byref(self._h), int(device))
+        if rc != _abi.OK:
+            msg = self._lib.ctr_last_error(None)
+            self._h = None
+            raise EngineError("ctr_create(device=%d) failed (%d): %s" % (
+                device, rc, (msg or b'').decode()))
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.ctr_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc != _abi.OK:
+            msg = (self._lib.ctr_last_error(self._h) or b'').decode()
+            if rc == _abi.ERR_INVALID:
+                raise ValueError("%s: %s" % (what, msg))
+            if rc == _abi.ERR_UNSUPPORTED:
+                raise NotImplementedError("%s: %s" % (what, msg))
+            raise EngineError("%s failed (%d): %s" % (what, rc, msg))
+
+    def refine_batch(self, problem, batch):
+        """Host-buffer call: ``batch`` is an ``_abi.HostBatch``; outputs are
+        written into its arrays."""
+        b = batch.as_struct()
+        self._check(self._lib.ctr_refine_batch(self._h, C.byref(problem), C.byref(b)),
+                    'ctr_refine_batch')
+        return batch
+
+    # ---- device-resident path (bench, multi-GPU driver) ---------------------
+    def plan(self, problem, feat_offset_host):
+        import numpy as np
+        off = np.ascontiguousarray(feat_offset_host, dtype=np.int32)
+        plan = C.c_void_p()
+        self._check(self._lib.ctr_plan_create(self._h, C.byref(problem), len(off) - 1,
+                                              off.ctypes.data, C.byref(plan)),
+                    'ctr_plan_create')
+        return Plan(self._lib, plan)
+
+    def refine_batch_device(self, plan, batch_struct, stream=None):
+        self._check(self._lib.ctr_refine_batch_device(
+            self._h, plan._p, C.byref(batch_struct), C.c_void_p(stream or 0)),
+            'ctr_refine_batch_device')
+
+    def frame_max_device(self, frames_ptr, dtype_code, n_frames, frame_elems, out_ptr,
+                         stream=None):
+        self._check(self._lib.ctr_frame_max_device(
+            self._h, C.c_void_p(frames_ptr), dtype_code, n_frames, frame_elems,
+            C.c_void_p(out_ptr), C.c_void_p(stream or 0)), 'ctr_frame_max_device')
+
+    def synchronize(self, stream=None):
+        self._check(self._lib.ctr_synchronize(self._h, C.c_void_p(stream or 0)),
+                    'ctr_synchronize')
+
+    def last_kernel_ms(self):
+        a, b = C.c_double(), C.c_double()
+        self._check(self._lib.ctr_last_kernel_ms(self._h, C.byref(a), C.byref(b)),
+                    'ctr_last_kernel_ms')
+        return a.value, b.value
+
+
+class Plan(object):
+    def __init__(self, lib, p):
+        self._lib, self._p = lib, p
+
+    def close(self):
+        if self._p:
+            self._lib.ctr_plan_destroy(self._p)
+            self._p = None
+
+    __del__ = close
+
+
+_default_engines = {}
+
+
+def default_engine(device=0):
+    eng = _default_engines.get(device)
+    if eng is None:
+        eng = _default_engines[device] = Engine(device)
+    return eng

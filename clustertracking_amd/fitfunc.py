@@ -1,0 +1,132 @@
+"""Host-side description of the fit model: parameter layout, modes, bounds.
+
+Mirrors the *metadata* half of reference ``clustertracking/fitfunc.py``
+(``FitFunctions.__init__`` :325-413, ``validate_bounds`` :492-533,
+``compute_bounds`` :535-558).  The arithmetic half (residual / gradient
+closures, :421-489) is what the HIP engine replaces and is not present here.
+"""
+import warnings
+
+import numpy as np
+
+from .utils import default_pos_columns, default_size_columns
+
+# reference fitfunc.py:9-11
+MODE_DICT = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 5, 6: 6,
+             'const': 0, 'var': 1, 'global': 2, 'cluster': 3,
+             'particle': 4, 'frame': 5}
+
+# enum shared with include/ctrefine.h (CTR_FIT_*)
+FIT_FUNCTION_CODES = {'gauss': 0, 'ring': 1, 'disc': 2, 'inv_series': 3}
+
+
+class FitFunctions(object):
+    """Parameter names/order and modes for one refine call.
+
+    Column order of the per-feature parameter matrix (reference
+    fitfunc.py:353-354): ``[background, signal, (z,) y, x, size | size_(z,)y,x]``.
+    Only the Gaussian profile is implemented by the engine; the other
+    reference profiles are recognised and rejected with a clear message.
+    """
+
+    def __init__(self, fit_function='gauss', ndim=2, isotropic=True,
+                 param_mode=None):
+        if isinstance(fit_function, dict):
+            raise NotImplementedError(
+                "custom (dict) fit functions need Python callbacks per "
+                "evaluation and are not supported by the MI355X engine")
+        if fit_function != 'gauss':
+            base = fit_function.rsplit('_', 1)[0] if fit_function not in \
+                FIT_FUNCTION_CODES else fit_function
+            if base in FIT_FUNCTION_CODES:
+                raise NotImplementedError(
+                    "fit_function %r is reserved in the C-ABI but not yet "
+                    "implemented by the MI355X engine (only 'gauss')" % fit_function)
+            raise ValueError("Unknown fit function {}".format(fit_function))
+        self.fit_function = fit_function
+        self.ndim = int(ndim)
+        self.isotropic = bool(isotropic)
+        self.pos_columns = default_pos_columns(ndim)
+        self.size_columns = default_size_columns(ndim, isotropic)
+        self._params = []
+        self.default = dict(background=0.)
+        self.params = ['background', 'signal'] + self.pos_columns + \
+            self.size_columns + self._params
+
+        # fitfunc.py:356-387
+        mode = dict(signal='var', background='cluster')
+        if param_mode is not None:
+            mode.update(param_mode)
+        if 'pos' in mode:
+            for col in self.pos_columns:
+                mode.setdefault(col, mode['pos'])
+            del mode['pos']
+        if (not isotropic) and ('size' in mode):
+            for col in self.size_columns:
+                mode.setdefault(col, mode['size'])
+            del mode['size']
+        mode = {key: MODE_DICT[val] for key, val in mode.items()}
+        for col in self.pos_columns:
+            mode.setdefault(col, 1)
+        for col in self.params:
+            mode.setdefault(col, 0)
+        # fitfunc.py:389-392
+        if mode['background'] == 1:
+            warnings.warn('The background param mode cannot vary per feature. '
+                          'Varying per cluster now.')
+            mode['background'] = 3
+        self.param_mode = mode
+        self.modes = [int(mode[p]) for p in self.params]
+
+    @property
+    def n_params(self):
+        return len(self.params)
+
+    def validate_bounds(self, bounds=None, radius=None):
+        """Three ``[2, n_params]`` templates: absolute, +-difference and
+        +-relative difference; NaN = no bound (reference fitfunc.py:492-533)."""
+        if bounds is None:
+            bounds = dict()
+        n = len(self.params)
+        tmpl_abs = np.empty((2, n), dtype=np.float64)
+        tmpl_diff = np.empty((2, n), dtype=np.float64)
+        tmpl_rel = np.empty((2, n), dtype=np.float64)
+        nan = np.nan
+        for i, name in enumerate(self.params):
+            b_abs = bounds.get(name, nan)
+            b_diff = bounds.get(name + '_diff', nan)
+            b_rel = bounds.get(name + '_rel_diff', nan)
+            for group, key in ((self.pos_columns, 'pos'), (self.size_columns, 'size')):
+                if name in group:
+                    if b_abs is nan:
+                        b_abs = bounds.get(key, nan)
+                    if b_diff is nan:
+                        b_diff = bounds.get(key + '_diff', nan)
+                    if b_rel is nan:
+                        b_rel = bounds.get(key + '_rel_diff', nan)
+            if b_abs is nan and name in ['background', 'signal'] + self.size_columns:
+                b_abs = (0., nan)          # positive by default (:518-521)
+            if b_diff is nan and name in self.pos_columns:
+                r = float(radius[self.pos_columns.index(name)])
+                b_diff = (r, r)            # stay inside the mask (:523-527)
+            tmpl_abs[:, i] = b_abs
+            tmpl_diff[:, i] = b_diff
+            tmpl_rel[:, i] = b_rel
+        return tmpl_abs, tmpl_diff, tmpl_rel
+
+    def feature_bounds(self, templates, params):
+        """Per-feature ``low, high [N, n_params]`` (reference
+        fitfunc.py:541-550, the part of ``compute_bounds`` before packing).
+        Packing to the per-cluster vector (min of lows / max of highs for
+        shared parameters, :554-557) happens inside the engine."""
+        b_abs, b_diff, b_rel = templates
+        params = np.asarray(params, dtype=np.float64)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            low = np.nanmax([params - b_diff[0], params * (1 - b_rel[0])], axis=0)
+            low = np.fmax(low, b_abs[0])
+            low[np.isnan(low)] = -np.inf
+            high = np.nanmin([params + b_diff[1], params * (1 + b_rel[1])], axis=0)
+            high = np.fmin(high, b_abs[1])
+            high[np.isnan(high)] = np.inf
+        return low, high

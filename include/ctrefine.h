@@ -1,0 +1,172 @@
+/* ctrefine.h -- C-ABI of the MI355X cluster-refinement engine.
+ *
+ * One batched call replaces the per-cluster Python loop of the reference
+ * (clustertracking/refine.py:343-430): for every (frame, cluster) group it
+ * cuts the pixel window (masks.py:30-68), builds the per-feature elliptical
+ * masks (refine.py:28-58), and minimises the sum-of-Gaussians least-squares
+ * objective (fitfunc.py:421-489) under the box bounds (fitfunc.py:535-558) and
+ * optional dimer/trimer/tetramer equality constraints (constraints.py:59-137),
+ * including the re-window rounds (refine.py:365-388) and the failure rules
+ * (refine.py:33-34,356-357,376-377,391-394,408-418).
+ *
+ * The reference has no FFI of its own: these entry points are
+ * what a ctypes binding in its refine.py would call between the host-side
+ * setup (refine.py:242-341) and the DataFrame write-back (refine.py:419-430).
+ * INTEGRATION.md shows that binding.
+ *
+ * Plain C types only; every buffer is caller-owned; calls are synchronous
+ * unless stated; per-cluster failures are DATA (status + NaN cost), never an
+ * error return (mirrors refine.py:408-418).
+ */
+#ifndef CTREFINE_H
+#define CTREFINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTR_ABI_VERSION 1
+#define CTR_MAX_NDIM 3
+#define CTR_MAX_PARAMS 8 /* background, signal, <=3 positions, <=3 sizes */
+#define CTR_MAX_VARS 127 /* optimiser variables per cluster (engine limit) */
+
+/* error codes (return values) */
+enum {
+  CTR_OK = 0,
+  CTR_ERR_INVALID = 1,     /* malformed descriptor (reference: ValueError / AssertionError, refine.py:256-262,283) */
+  CTR_ERR_UNSUPPORTED = 2, /* recognised but not implemented (mode 'global', non-gauss profile) */
+  CTR_ERR_DEVICE = 3,      /* HIP runtime failure, no MI355X visible, ... */
+  CTR_ERR_NOMEM = 4
+};
+
+/* pixel types of the frame block */
+enum {
+  CTR_DTYPE_U8 = 0,
+  CTR_DTYPE_U16 = 1,
+  CTR_DTYPE_I16 = 2,
+  CTR_DTYPE_I32 = 3,
+  CTR_DTYPE_F32 = 4,
+  CTR_DTYPE_F64 = 5
+};
+
+/* radial profile (fitfunc.py:195-204); only GAUSS is implemented */
+enum { CTR_FIT_GAUSS = 0, CTR_FIT_RING = 1, CTR_FIT_DISC = 2, CTR_FIT_INV_SERIES = 3 };
+
+/* parameter modes (fitfunc.py:9-11); 2 ('global') is rejected: it couples all
+ * clusters into one problem (refine.py:319-332) and does not shard */
+enum { CTR_MODE_CONST = 0, CTR_MODE_VAR = 1, CTR_MODE_GLOBAL = 2, CTR_MODE_CLUSTER = 3 };
+
+/* equality constraints (constraints.py:59-137); applied only to clusters of
+ * exactly 2 / 3 / 4 features (constraints.py:32-34) */
+enum { CTR_CONS_NONE = 0, CTR_CONS_DIMER = 1, CTR_CONS_TRIMER = 2, CTR_CONS_TETRAMER = 3 };
+
+/* per-cluster status */
+enum {
+  CTR_STATUS_OK = 0,
+  CTR_STATUS_OUT_OF_BOUNDS = 1, /* no coordinate inside the frame (refine.py:33-34) or empty mask */
+  CTR_STATUS_NONFINITE = 2,     /* non-finite initial parameters (refine.py:356-357) */
+  CTR_STATUS_NO_CONVERGENCE = 3,/* solver failed / iteration limit (refine.py:376-377) */
+  CTR_STATUS_RMS_DEV = 4,       /* rms deviation above max_rms_dev (refine.py:391-394) */
+  CTR_STATUS_TOO_LARGE = 5      /* more than CTR_MAX_VARS variables (engine limit) */
+};
+
+/* What is fitted and how (one per call). */
+typedef struct ctr_problem {
+  int32_t ndim;                    /* 2 or 3 */
+  int32_t isotropic;               /* 1: one 'size' column; 0: one per axis */
+  int32_t fit_function;            /* CTR_FIT_* */
+  int32_t n_params;                /* 2 + ndim + (isotropic ? 1 : ndim); column order
+                                      [background, signal, (z,) y, x, size | size_(z,)y,x]
+                                      (fitfunc.py:353-354) */
+  int32_t modes[CTR_MAX_PARAMS];   /* CTR_MODE_* per column (fitfunc.py:394) */
+  int32_t radius[CTR_MAX_NDIM];    /* mask radius per axis = diameter // 2 (refine.py:286) */
+  int32_t constraint_kind;         /* CTR_CONS_* */
+  int32_t max_iter;                /* re-window rounds, >= 1 (refine.py:365; default 10) */
+  int32_t solver_maxiter;          /* solver iterations per round (refine.py:243; default 100) */
+  int32_t reserved0;
+  double constraint_dist[CTR_MAX_NDIM]; /* per-axis distance of the constraint */
+  double max_shift;                /* refine.py:384 (default 1) */
+  double max_rms_dev;              /* refine.py:391 (default 1) */
+  double residual_factor;          /* refine.py:354,379 (default 1e5) */
+  double xtol;                     /* relative step tolerance; <= 0 -> 1e-9 */
+  double ftol;                     /* relative model-decrease tolerance; <= 0 -> 1e-14 */
+  double reserved1;
+} ctr_problem;
+
+/* The data of one batch.  All arrays C-contiguous.  For ctr_refine_batch the
+ * pointers are HOST pointers; for ctr_refine_batch_device they are DEVICE
+ * pointers (hipMalloc'ed memory of the handle's device). */
+typedef struct ctr_batch {
+  const void* frames;          /* [n_frames, shape...] pixels, dtype frame_dtype */
+  int32_t frame_dtype;         /* CTR_DTYPE_* */
+  int32_t reserved0;
+  int64_t n_frames;
+  int64_t shape[CTR_MAX_NDIM]; /* frame shape (z,) y, x; first ndim entries used */
+  int64_t n_clusters;          /* C */
+  int64_t n_features;          /* N */
+  const int32_t* frame_index;  /* [C] index into frames of each cluster */
+  const int32_t* feat_offset;  /* [C+1] CSR offsets into the feature table */
+  const double* params;        /* [N, n_params] initial parameters (refine.py:345) */
+  const double* low;           /* [N, n_params] per-feature lower bounds (fitfunc.py:541-546), -inf = none */
+  const double* high;          /* [N, n_params] per-feature upper bounds (fitfunc.py:547-550), +inf = none */
+  double* params_out;          /* [N, n_params] refined; equals params for failed clusters */
+  double* cost;                /* [C] rms residual / frame max (refine.py:379); NaN on failure */
+  int32_t* status;             /* [C] CTR_STATUS_* */
+  int32_t* n_rounds;           /* [C] re-window rounds used */
+  int32_t* n_iter;             /* [C] solver iterations, summed over rounds */
+} ctr_batch;
+
+typedef struct ctr_handle ctr_handle;
+typedef struct ctr_plan ctr_plan;
+
+/* ABI version of the loaded library (== CTR_ABI_VERSION). */
+int ctr_abi_version(void);
+
+/* Create / destroy an engine bound to one HIP device.  Owns streams and
+ * scratch buffers.  One caller thread at a time per handle. */
+int ctr_create(ctr_handle** out, int device);
+void ctr_destroy(ctr_handle* h);
+
+/* Last error text of a failed call on this handle (or of ctr_create when h is NULL). */
+const char* ctr_last_error(const ctr_handle* h);
+
+/* Validate a problem descriptor without touching a device. */
+int ctr_validate_problem(const ctr_problem* p, char* msg, int msg_len);
+
+/* Number of optimiser variables of a cluster with n features
+ * (vect_from_params layout, fitfunc.py:207-263, groups=None). */
+int ctr_cluster_n_vars(const ctr_problem* p, int n_features);
+
+/* Host-pointer entry: copies the batch to the device, runs it, copies the
+ * results back.  Synchronous.  Replaces refine.py:343-430. */
+int ctr_refine_batch(ctr_handle* h, const ctr_problem* p, const ctr_batch* b);
+
+/* Device-resident path (inputs already in HBM, e.g. frames produced on the
+ * GPU): a plan bins the clusters of a batch by problem size on the host once;
+ * the run is asynchronous on the given HIP stream (hipStream_t passed as
+ * void*; NULL = the handle's own stream). */
+int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
+                    const int32_t* feat_offset_host, ctr_plan** out);
+void ctr_plan_destroy(ctr_plan* plan);
+int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan,
+                            const ctr_batch* b_device, void* hip_stream);
+
+/* Per-frame maximum on the device (the norm of refine.py:354); part of
+ * ctr_refine_batch_device, exposed for measurement.  out_max: [n_frames] f64. */
+int ctr_frame_max_device(ctr_handle* h, const void* frames, int32_t frame_dtype,
+                         int64_t n_frames, int64_t frame_elems, double* out_max,
+                         void* hip_stream);
+
+/* Block until the work queued by the *_device calls on `hip_stream` is done. */
+int ctr_synchronize(ctr_handle* h, void* hip_stream);
+
+/* Timing of the kernels of the last ctr_refine_batch_device call, measured
+ * with HIP events on the launch stream (milliseconds); synchronises. */
+int ctr_last_kernel_ms(ctr_handle* h, double* frame_max_ms, double* refine_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTREFINE_H */

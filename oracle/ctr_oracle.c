@@ -1,0 +1,691 @@
+/* ctr_oracle.c -- CPU restatement of the refine hot path.  TEST INFRASTRUCTURE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this; the product (clustertracking_amd + libctrefine.so) never does.
+ *
+ * What follows the reference line by line (and is pinned by the golden
+ * fixtures generated from the reference, tests/golden/):
+ *   window()            masks.py:30-68     (round-half-even, in-bounds filter, clip)
+ *   in_mask()           refine.py:43-44    (ellipse on the UNROUNDED coords, <= 1)
+ *   union / P           refine.py:47-58    (P = pixels in the union mask)
+ *   layout / pack       fitfunc.py:207-315 (parameter-major vector, groups=None)
+ *   model + derivatives fitfunc.py:14-118  (r2_*, dr2_*, gauss_func/gauss_dfunc)
+ *   objective, gradient fitfunc.py:436-487 (each feature only inside its own mask)
+ *   packed bounds       fitfunc.py:554-557 (shared parameter: min of lows, max of highs)
+ *   constraints         constraints.py:59-137 (dimer, trimer, tetramer)
+ *   round loop, rules   refine.py:343-430
+ *
+ * What does NOT follow the reference: the minimiser.  The reference hands the
+ * scalar objective to scipy.optimize.minimize(method='SLSQP', tol=1e-6)
+ * (refine.py:373-375; SciPy is a third-party dependency, not in the repo).
+ * Here -- exactly as in the HIP engine this file checks -- the same objective
+ * is minimised under the same bounds/constraints by a bounded Levenberg-
+ * Marquardt iteration on the residual vector (active set for the box,
+ * range-space SQP step for the equality constraints).  Parity of the fitted
+ * parameters with the reference is therefore "same minimiser of the same
+ * problem", pinned by the fixtures' converged reference output (oracle B,
+ * tol=1e-14) and bounded by the reference's own default-tolerance scatter
+ * (oracle A).  The faithful SLSQP restatement is oracle/ref_numpy.py.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ctrefine.h"
+
+#define MAXV CTR_MAX_VARS
+#define MAXC 6 /* equality constraints per cluster */
+
+typedef struct {
+  int n, nd, np, nv, nsz;
+  int var_of[CTR_MAX_PARAMS];   /* first variable of the column, -1 if constant */
+  int per_feat[CTR_MAX_PARAMS]; /* 1: one variable per feature (mode 'var') */
+} layout_t;
+
+typedef struct {
+  const ctr_problem* p;
+  const ctr_batch* b;
+  layout_t L;
+  const double* pconst; /* [n][np] parameters supplying the constants */
+  const void* frame;    /* pixels of this cluster's frame */
+  int origin[3], wshape[3];
+  const double* mcoords; /* [n][nd] coordinates the masks are centred on */
+  int n_cons;            /* active equality constraints (0 if size mismatch) */
+} ctx_t;
+
+/* ---- small helpers ------------------------------------------------------- */
+
+static double pixel(const void* base, int dtype, size_t i) {
+  switch (dtype) {
+    case CTR_DTYPE_U8: return (double)((const uint8_t*)base)[i];
+    case CTR_DTYPE_U16: return (double)((const uint16_t*)base)[i];
+    case CTR_DTYPE_I16: return (double)((const int16_t*)base)[i];
+    case CTR_DTYPE_I32: return (double)((const int32_t*)base)[i];
+    case CTR_DTYPE_F32: return (double)((const float*)base)[i];
+    default: return ((const double*)base)[i];
+  }
+}
+
+static size_t dtype_size(int dtype) {
+  switch (dtype) {
+    case CTR_DTYPE_U8: return 1;
+    case CTR_DTYPE_U16: case CTR_DTYPE_I16: return 2;
+    case CTR_DTYPE_I32: case CTR_DTYPE_F32: return 4;
+    default: return 8;
+  }
+}
+
+static int make_layout(const ctr_problem* p, int n, layout_t* L) {
+  int nv = 0;
+  L->n = n; L->nd = p->ndim; L->np = p->n_params;
+  L->nsz = p->isotropic ? 1 : p->ndim;
+  for (int k = 0; k < p->n_params; ++k) {
+    int m = p->modes[k];
+    if (m == CTR_MODE_CONST) { L->var_of[k] = -1; L->per_feat[k] = 0; }
+    else if (m == CTR_MODE_VAR) { L->var_of[k] = nv; L->per_feat[k] = 1; nv += n; }
+    else { L->var_of[k] = nv; L->per_feat[k] = 0; nv += 1; } /* groups=None: one per cluster */
+  }
+  L->nv = nv;
+  return nv;
+}
+
+int ctro_cluster_n_vars(const ctr_problem* p, int n) {
+  layout_t L;
+  return make_layout(p, n, &L);
+}
+
+/* parameter k of feature i at the trial vector v */
+static inline double par(const ctx_t* c, const double* v, int i, int k) {
+  int b = c->L.var_of[k];
+  if (b < 0) return c->pconst[i * c->L.np + k];
+  return v[b + (c->L.per_feat[k] ? i : 0)];
+}
+
+/* masks.py:42-68.  Returns 0 when no coordinate is inside the frame. */
+static int window(int nd, const int64_t* shape, const int32_t* radius,
+                  const double* coords, int n, int* origin, int* wshape) {
+  long lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  int any = 0;
+  for (int i = 0; i < n; ++i) {
+    long ci[3];
+    int ok = 1;
+    for (int a = 0; a < nd; ++a) {
+      double r = nearbyint(coords[i * nd + a]); /* default rounding mode: half to even (masks.py:54) */
+      ci[a] = (long)r;
+      if (!(ci[a] >= -(long)radius[a] && ci[a] < (long)shape[a] + radius[a])) ok = 0;
+    }
+    if (!ok) continue;
+    for (int a = 0; a < nd; ++a) {
+      if (!any || ci[a] < lo[a]) lo[a] = ci[a];
+      if (!any || ci[a] > hi[a]) hi[a] = ci[a];
+    }
+    any = 1;
+  }
+  if (!any) return 0;
+  for (int a = 0; a < nd; ++a) {
+    long l = lo[a] - radius[a], u = hi[a] + radius[a] + 1;
+    if (l < 0) l = 0;
+    if (u > shape[a]) u = shape[a];
+    origin[a] = (int)l;
+    wshape[a] = (int)(u - l);
+  }
+  return 1;
+}
+
+int ctro_window(int nd, const int64_t* shape, const int32_t* radius,
+                const double* coords, int n, int32_t* origin, int32_t* wshape) {
+  int o[3], w[3];
+  if (!window(nd, shape, radius, coords, n, o, w)) return 0;
+  for (int a = 0; a < nd; ++a) { origin[a] = o[a]; wshape[a] = w[a]; }
+  return 1;
+}
+
+/* refine.py:43: sum(((idx - (coord - origin)) / radius)**2) <= 1, no FMA */
+#pragma GCC push_options
+#pragma GCC optimize("fp-contract=off")
+static inline int in_mask(int nd, const int* idx, const double* coord,
+                          const int* origin, const int32_t* radius) {
+  double s = 0.;
+  for (int a = 0; a < nd; ++a) {
+    double rel = coord[a] - (double)origin[a];
+    double t = ((double)idx[a] - rel) / (double)radius[a];
+    double t2 = t * t;
+    s = s + t2;
+  }
+  return s <= 1.;
+}
+#pragma GCC pop_options
+
+/* mask pixel counts (for known-answer tests): P and per-feature counts */
+long ctro_mask_counts(int nd, const int64_t* shape, const int32_t* radius,
+                      const double* coords, int n, int64_t* per_feature) {
+  int origin[3], ws[3] = {1, 1, 1}, idx[3];
+  long P = 0;
+  if (!window(nd, shape, radius, coords, n, origin, ws)) return -1;
+  for (int i = 0; i < n; ++i) per_feature[i] = 0;
+  int w0 = nd == 3 ? ws[0] : 1, w1 = ws[nd - 2], w2 = ws[nd - 1];
+  for (int z = 0; z < w0; ++z)
+    for (int y = 0; y < w1; ++y)
+      for (int x = 0; x < w2; ++x) {
+        int any = 0;
+        if (nd == 3) { idx[0] = z; idx[1] = y; idx[2] = x; } else { idx[0] = y; idx[1] = x; }
+        for (int i = 0; i < n; ++i)
+          if (in_mask(nd, idx, coords + i * nd, origin, radius)) { per_feature[i]++; any = 1; }
+        P += any;
+      }
+  return P;
+}
+
+/* ---- constraints (constraints.py:59-137) --------------------------------- */
+
+static const int PAIRS[6][2] = {{0, 1}, {1, 2}, {0, 2}, {1, 3}, {0, 3}, {2, 3}};
+
+static int n_constraints(const ctr_problem* p, int n) {
+  switch (p->constraint_kind) {
+    case CTR_CONS_DIMER: return n == 2 ? 1 : 0;
+    case CTR_CONS_TRIMER: return n == 3 ? 3 : 0;
+    case CTR_CONS_TETRAMER: return n == 4 ? (p->ndim == 2 ? 4 : 6) : 0;
+    default: return 0;
+  }
+}
+
+/* c[m] and Jacobian Cj[m][nv] at v */
+static void eval_constraints(const ctx_t* c, const double* v, double* cv, double* Cj) {
+  const int nd = c->L.nd, nv = c->L.nv, m = c->n_cons;
+  int npairs = c->p->constraint_kind == CTR_CONS_DIMER ? 1
+             : c->p->constraint_kind == CTR_CONS_TRIMER ? 3 : 6;
+  double d2[6];
+  int order[6];
+  if (m == 0) return;
+  for (int q = 0; q < npairs; ++q) {
+    double s = 0.;
+    for (int a = 0; a < nd; ++a) {
+      double t = (par(c, v, PAIRS[q][0], 2 + a) - par(c, v, PAIRS[q][1], 2 + a)) /
+                 c->p->constraint_dist[a];
+      s += t * t;
+    }
+    d2[q] = s;
+    order[q] = q;
+  }
+  if (c->p->constraint_kind == CTR_CONS_TETRAMER && nd == 2) {
+    /* the 4 smallest of the 6 pair distances (constraints.py:102-114) */
+    for (int i = 1; i < 6; ++i) {
+      int o = order[i], j = i - 1;
+      while (j >= 0 && d2[order[j]] > d2[o]) { order[j + 1] = order[j]; --j; }
+      order[j + 1] = o;
+    }
+  }
+  memset(Cj, 0, sizeof(double) * (size_t)m * nv);
+  for (int r = 0; r < m; ++r) {
+    int q = order[r];
+    int i0 = PAIRS[q][0], i1 = PAIRS[q][1];
+    cv[r] = 1. - d2[q];
+    for (int a = 0; a < nd; ++a) {
+      int k = 2 + a, b = c->L.var_of[k];
+      if (b < 0) continue;
+      double da = c->p->constraint_dist[a];
+      double t = -2. * (par(c, v, i0, k) - par(c, v, i1, k)) / (da * da);
+      Cj[r * nv + b + (c->L.per_feat[k] ? i0 : 0)] += t;
+      Cj[r * nv + b + (c->L.per_feat[k] ? i1 : 0)] -= t;
+    }
+  }
+}
+
+/* ---- objective: S = sum r^2, g = J^T r, A = J^T J ------------------------- */
+
+static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double* g,
+                         double* A, long* P_out) {
+  const layout_t* L = &c->L;
+  const int nd = L->nd, nv = L->nv, n = L->n, np = L->np;
+  const int64_t* fshape = c->b->shape;
+  const int dtype = c->b->frame_dtype;
+  double prm[CTR_MAX_PARAMS];
+  double row[MAXV];
+  int nz[MAXV];
+  double S = 0.;
+  long P = 0;
+  const int bgvar = L->var_of[0];
+  const double bg = par(c, v, 0, 0);
+  const int w0 = nd == 3 ? c->wshape[0] : 1, w1 = c->wshape[nd - 2], w2 = c->wshape[nd - 1];
+  if (g) memset(g, 0, sizeof(double) * nv);
+  if (A) memset(A, 0, sizeof(double) * nv * nv);
+  for (int z = 0; z < w0; ++z)
+    for (int y = 0; y < w1; ++y)
+      for (int x = 0; x < w2; ++x) {
+        int idx[3];
+        double mesh[3];
+        size_t off;
+        int any = 0, nnz = 0;
+        double res = 0.;
+        if (nd == 3) {
+          idx[0] = z; idx[1] = y; idx[2] = x;
+          off = ((size_t)(z + c->origin[0]) * fshape[1] + (y + c->origin[1])) * fshape[2] + (x + c->origin[2]);
+        } else {
+          idx[0] = y; idx[1] = x;
+          off = (size_t)(y + c->origin[0]) * fshape[1] + (x + c->origin[1]);
+        }
+        for (int a = 0; a < nd; ++a) mesh[a] = (double)(idx[a] + c->origin[a]);
+        for (int i = 0; i < n; ++i) {
+          if (!in_mask(nd, idx, c->mcoords + i * nd, c->origin, c->p->radius)) continue;
+          if (!any) {
+            any = 1;
+            res = pixel(c->frame, dtype, off) - bg;
+            if (bgvar >= 0) { row[bgvar] = -1.; nz[nnz++] = bgvar; }
+          }
+          for (int k = 1; k < np; ++k) prm[k] = par(c, v, i, k);
+          const double sig = prm[1];
+          double r2 = 0., dr2[6];
+          if (c->p->isotropic) {
+            const double size = prm[2 + nd];
+            double q = 0.;
+            for (int a = nd - 1; a >= 0; --a) { /* x first (fitfunc.py:17,40) */
+              double d = mesh[a] - prm[2 + a];
+              q += d * d;
+            }
+            r2 = q / (size * size);
+            for (int a = 0; a < nd; ++a) dr2[a] = (prm[2 + a] - mesh[a]) * (2. / (size * size));
+            dr2[nd] = q * (-2. / (size * size * size));
+          } else {
+            for (int a = nd - 1; a >= 0; --a) {
+              double d = mesh[a] - prm[2 + a], sz = prm[2 + nd + a];
+              r2 += d * d / (sz * sz);
+              dr2[a] = (prm[2 + a] - mesh[a]) * (2. / (sz * sz));
+              dr2[nd + a] = d * d * (-2. / (sz * sz * sz));
+            }
+          }
+          const double gv = exp(-0.5 * nd * r2); /* fitfunc.py:112-118 */
+          const double dg = -0.5 * nd * gv;
+          res -= sig * gv;
+          if (g) {
+            /* d res / d signal, positions, sizes (fitfunc.py:475-478, sign of the residual) */
+            double d[1 + 6];
+            d[0] = -gv;
+            for (int t = 0; t < nd + L->nsz; ++t) d[1 + t] = -sig * dg * dr2[t];
+            for (int k = 1; k < np; ++k) {
+              int b = L->var_of[k];
+              if (b < 0) continue;
+              int col = b + (L->per_feat[k] ? i : 0);
+              int seen = 0;
+              for (int t = 0; t < nnz; ++t) if (nz[t] == col) { seen = 1; break; }
+              if (seen) row[col] += d[k - 1];
+              else { row[col] = d[k - 1]; nz[nnz++] = col; }
+            }
+          }
+        }
+        if (!any) continue;
+        ++P;
+        if (res != res) continue; /* nansum (fitfunc.py:449,483) */
+        S += res * res;
+        if (g) {
+          for (int s = 0; s < nnz; ++s) {
+            int cs = nz[s];
+            double rs = row[cs];
+            g[cs] += rs * res;
+            for (int t = 0; t < nnz; ++t) A[cs * nv + nz[t]] += rs * row[nz[t]];
+          }
+        }
+      }
+  *S_out = S;
+  *P_out = P;
+}
+
+/* ---- dense helpers -------------------------------------------------------- */
+
+/* in-place lower Cholesky of H[n][n] (row stride ld); 0 on failure */
+static int cholesky(double* H, int n, int ld) {
+  for (int j = 0; j < n; ++j) {
+    double d = H[j * ld + j];
+    for (int k = 0; k < j; ++k) d -= H[j * ld + k] * H[j * ld + k];
+    if (!(d > 0.) || !isfinite(d)) return 0;
+    d = sqrt(d);
+    H[j * ld + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = H[i * ld + j];
+      for (int k = 0; k < j; ++k) s -= H[i * ld + k] * H[j * ld + k];
+      H[i * ld + j] = s / d;
+    }
+  }
+  return 1;
+}
+
+static void chol_solve(const double* Lm, int n, int ld, double* x) {
+  for (int i = 0; i < n; ++i) {
+    double s = x[i];
+    for (int k = 0; k < i; ++k) s -= Lm[i * ld + k] * x[k];
+    x[i] = s / Lm[i * ld + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = x[i];
+    for (int k = i + 1; k < n; ++k) s -= Lm[k * ld + i] * x[k];
+    x[i] = s / Lm[i * ld + i];
+  }
+}
+
+/* ---- bounded (+ equality constrained) Levenberg-Marquardt ----------------- */
+
+typedef struct { double S; long P; int iters; int ok; } solve_t;
+
+static double l1norm(const double* c, int m) {
+  double s = 0.;
+  for (int i = 0; i < m; ++i) s += fabs(c[i]);
+  return s;
+}
+
+static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const double* hi,
+                     double* v /* out */) {
+  const int nv = c->L.nv, m = c->n_cons;
+  const int maxiter = c->p->solver_maxiter > 0 ? c->p->solver_maxiter : 100;
+  const double xtol = c->p->xtol > 0 ? c->p->xtol : 1e-9;
+  const double ftol = c->p->ftol > 0 ? c->p->ftol : 1e-14;
+  solve_t out = {NAN, 0, 0, 0};
+  double *g = malloc(sizeof(double) * nv), *A = malloc(sizeof(double) * nv * nv);
+  double *gt = malloc(sizeof(double) * nv), *At = malloc(sizeof(double) * nv * nv);
+  double *H = malloc(sizeof(double) * nv * nv), *vt = malloc(sizeof(double) * nv);
+  double *dl = malloc(sizeof(double) * nv), *w = malloc(sizeof(double) * nv);
+  double *Y = malloc(sizeof(double) * nv * MAXC), *Cj = malloc(sizeof(double) * nv * MAXC);
+  double *Cjt = malloc(sizeof(double) * nv * MAXC);
+  int* fr = malloc(sizeof(int) * nv);
+  double cv[MAXC], cvt[MAXC], mult[MAXC], Sc[MAXC * MAXC];
+  double S, St, mu, nu = 2., sigma = 0.;
+  long P;
+  int last_accepted = 1;
+
+  for (int i = 0; i < nv; ++i) {
+    if (lo[i] > hi[i]) goto done; /* infeasible box (SciPy raises ValueError) */
+    v[i] = v0[i] < lo[i] ? lo[i] : (v0[i] > hi[i] ? hi[i] : v0[i]);
+  }
+  eval_cluster(c, v, &S, g, A, &P);
+  out.P = P;
+  if (P == 0 || !isfinite(S)) goto done;
+  eval_constraints(c, v, cv, Cj);
+  memset(mult, 0, sizeof mult);
+  mu = 1e-3; /* multiplies the Marquardt diagonal below */
+
+  for (int it = 0; it < maxiter; ++it) {
+    int nf = 0;
+    out.iters = it + 1;
+    /* active set: fixed if at a bound and the Lagrangian gradient pushes outward */
+    for (int i = 0; i < nv; ++i) {
+      double gl = g[i];
+      for (int r = 0; r < m; ++r) gl += Cj[r * nv + i] * mult[r];
+      int fixed = (lo[i] == hi[i]) || (v[i] <= lo[i] && gl > 0.) || (v[i] >= hi[i] && gl < 0.);
+      if (!fixed) fr[nf++] = i;
+    }
+    if (nf == 0) { out.ok = 1; break; }
+    for (int a = 0; a < nf; ++a) {
+      for (int b = 0; b <= a; ++b) H[a * nf + b] = A[fr[a] * nv + fr[b]];
+      double d = A[fr[a] * nv + fr[a]];
+      H[a * nf + a] += mu * (d > 1e-300 ? d : 1.);
+    }
+    if (!cholesky(H, nf, nf)) { mu *= nu; nu *= 2.; last_accepted = 0; if (mu > 1e30) break; continue; }
+    for (int a = 0; a < nf; ++a) w[a] = g[fr[a]];
+    chol_solve(H, nf, nf, w); /* w = H^-1 g_F */
+    memset(dl, 0, sizeof(double) * nv);
+    if (m == 0) {
+      for (int a = 0; a < nf; ++a) dl[fr[a]] = -w[a];
+    } else {
+      /* range-space step: (C H^-1 C^T) mult = c - C H^-1 g ; d = -H^-1 (g + C^T mult) */
+      for (int r = 0; r < m; ++r) {
+        for (int a = 0; a < nf; ++a) Y[r * nf + a] = Cj[r * nv + fr[a]];
+        chol_solve(H, nf, nf, Y + r * nf);
+      }
+      for (int r = 0; r < m; ++r) {
+        for (int s = 0; s <= r; ++s) {
+          double t = 0.;
+          for (int a = 0; a < nf; ++a) t += Cj[r * nv + fr[a]] * Y[s * nf + a];
+          Sc[r * m + s] = t;
+        }
+        double t = cv[r];
+        for (int a = 0; a < nf; ++a) t -= Cj[r * nv + fr[a]] * w[a];
+        mult[r] = t;
+      }
+      {
+        double tr = 0.;
+        for (int r = 0; r < m; ++r) tr += Sc[r * m + r];
+        for (int r = 0; r < m; ++r) Sc[r * m + r] += 1e-14 * tr + 1e-300;
+      }
+      if (!cholesky(Sc, m, m)) { mu *= nu; nu *= 2.; last_accepted = 0; memset(mult, 0, sizeof mult); if (mu > 1e30) break; continue; }
+      chol_solve(Sc, m, m, mult);
+      for (int a = 0; a < nf; ++a) {
+        double t = w[a];
+        for (int r = 0; r < m; ++r) t += Y[r * nf + a] * mult[r];
+        dl[fr[a]] = -t;
+      }
+    }
+    /* projected trial point */
+    double stepmax = 0., gd = 0., dAd = 0.;
+    for (int i = 0; i < nv; ++i) {
+      double t = v[i] + dl[i];
+      t = t < lo[i] ? lo[i] : (t > hi[i] ? hi[i] : t);
+      vt[i] = t;
+      dl[i] = t - v[i];
+      double rel = fabs(dl[i]) / (fabs(v[i]) + 1.);
+      if (rel > stepmax) stepmax = rel;
+    }
+    for (int i = 0; i < nv; ++i) {
+      double t = 0.;
+      for (int j = 0; j < nv; ++j) t += A[i * nv + j] * dl[j];
+      dAd += dl[i] * t;
+      gd += g[i] * dl[i];
+    }
+    double pred = -(gd + 0.5 * dAd);
+    double cn = l1norm(cv, m), cn_lin = 0.;
+    if (m) {
+      double mmax = 0.;
+      for (int r = 0; r < m; ++r) {
+        double t = cv[r];
+        for (int i = 0; i < nv; ++i) t += Cj[r * nv + i] * dl[i];
+        cn_lin += fabs(t);
+        if (fabs(mult[r]) > mmax) mmax = fabs(mult[r]);
+      }
+      if (sigma < 2. * mmax) sigma = 2. * mmax;
+      pred += sigma * (cn - cn_lin);
+    }
+    /* converged: negligible step after an accepted one, or negligible model decrease */
+    int feasible = (m == 0) || (cn <= 1e-10);
+    if (feasible && ((last_accepted && stepmax <= xtol) || pred <= ftol * (0.5 * S) + 1e-300)) {
+      out.ok = 1;
+      break;
+    }
+    eval_cluster(c, vt, &St, gt, At, &P);
+    eval_constraints(c, vt, cvt, Cjt);
+    double act = 0.5 * (S - St) + (m ? sigma * (cn - l1norm(cvt, m)) : 0.);
+    if (isfinite(St) && pred > 0. && act > 0.) {
+      double rho = act / pred, t = 2. * rho - 1.;
+      double f = 1. - t * t * t;
+      mu *= f > 1. / 3. ? f : 1. / 3.;
+      nu = 2.;
+      memcpy(v, vt, sizeof(double) * nv);
+      memcpy(g, gt, sizeof(double) * nv);
+      memcpy(A, At, sizeof(double) * nv * nv);
+      memcpy(cv, cvt, sizeof(double) * (m ? m : 1));
+      memcpy(Cj, Cjt, sizeof(double) * (size_t)(m ? m : 0) * nv);
+      S = St;
+      last_accepted = 1;
+    } else {
+      mu *= nu;
+      nu *= 2.;
+      last_accepted = 0;
+      if (mu > 1e30) break;
+    }
+  }
+  out.S = S;
+done:
+  free(g); free(A); free(gt); free(At); free(H); free(vt); free(dl); free(w);
+  free(Y); free(Cj); free(Cjt); free(fr);
+  return out;
+}
+
+/* ---- one cluster (refine.py:343-430) -------------------------------------- */
+
+static void pack_start(const ctx_t* c, const double* params, const double* low,
+                       const double* high, double* v0, double* lo, double* hi) {
+  const layout_t* L = &c->L;
+  for (int k = 0; k < L->np; ++k) {
+    int b = L->var_of[k];
+    if (b < 0) continue;
+    if (L->per_feat[k]) {
+      for (int i = 0; i < L->n; ++i) {
+        v0[b + i] = params[i * L->np + k];
+        lo[b + i] = low[i * L->np + k];
+        hi[b + i] = high[i * L->np + k];
+      }
+    } else {
+      /* mean start (refine.py:361), loosest bound (fitfunc.py:554-557) */
+      double s = 0., l = INFINITY, h = -INFINITY;
+      for (int i = 0; i < L->n; ++i) {
+        s += params[i * L->np + k];
+        if (low[i * L->np + k] < l) l = low[i * L->np + k];
+        if (high[i * L->np + k] > h) h = high[i * L->np + k];
+      }
+      v0[b] = s / L->n;
+      lo[b] = l;
+      hi[b] = h;
+    }
+  }
+}
+
+static void refine_one(const ctr_problem* p, const ctr_batch* b, int64_t cl,
+                       const double* fmax) {
+  const int32_t f0 = b->feat_offset[cl], f1 = b->feat_offset[cl + 1];
+  const int n = f1 - f0, np = p->n_params, nd = p->ndim;
+  const double* params = b->params + (size_t)f0 * np;
+  double* pout = b->params_out + (size_t)f0 * np;
+  ctx_t c;
+  size_t felems = 1;
+  memcpy(pout, params, sizeof(double) * (size_t)n * np);
+  b->cost[cl] = NAN;
+  b->n_rounds[cl] = 0;
+  b->n_iter[cl] = 0;
+  c.p = p; c.b = b;
+  if (n <= 0) { b->status[cl] = CTR_STATUS_OUT_OF_BOUNDS; return; }
+  if (make_layout(p, n, &c.L) > MAXV) { b->status[cl] = CTR_STATUS_TOO_LARGE; return; }
+  for (int i = 0; i < n * np; ++i)
+    if (!isfinite(params[i])) { b->status[cl] = CTR_STATUS_NONFINITE; return; } /* refine.py:356-357 */
+  for (int a = 0; a < nd; ++a) felems *= (size_t)b->shape[a];
+  c.frame = (const char*)b->frames + (size_t)b->frame_index[cl] * felems * dtype_size(b->frame_dtype);
+  c.n_cons = n_constraints(p, n);
+  {
+    const int nv = c.L.nv;
+    double v0[MAXV], lo[MAXV], hi[MAXV], v[MAXV];
+    double* cur = malloc(sizeof(double) * (size_t)n * np);   /* params after the latest round */
+    double* coords = malloc(sizeof(double) * (size_t)n * nd);
+    const double fm = fmax[b->frame_index[cl]];
+    const double norm = fm * fm / p->residual_factor;          /* refine.py:354 */
+    double rms = NAN;
+    int status = CTR_STATUS_OK;
+    memcpy(cur, params, sizeof(double) * (size_t)n * np);
+    for (int i = 0; i < n; ++i)
+      for (int a = 0; a < nd; ++a) coords[i * nd + a] = params[i * np + 2 + a];
+    c.pconst = cur;
+    pack_start(&c, params, b->low + (size_t)f0 * np, b->high + (size_t)f0 * np, v0, lo, hi);
+    for (int round = 0; round < p->max_iter; ++round) {
+      b->n_rounds[cl] = round + 1;
+      if (!window(nd, b->shape, p->radius, coords, n, c.origin, c.wshape)) {
+        status = CTR_STATUS_OUT_OF_BOUNDS;                      /* refine.py:33-34 */
+        break;
+      }
+      c.mcoords = coords;
+      solve_t r = solve(&c, v0, lo, hi, v);
+      b->n_iter[cl] += r.iters;
+      if (r.P == 0) { status = CTR_STATUS_OUT_OF_BOUNDS; break; }
+      if (!r.ok) { status = CTR_STATUS_NO_CONVERGENCE; break; } /* refine.py:376-377 */
+      rms = sqrt(((r.S / (double)r.P) / norm) / p->residual_factor); /* refine.py:379 */
+      int moved = 0;
+      for (int i = 0; i < n; ++i) {
+        double d2 = 0.;
+        for (int k = 0; k < np; ++k) cur[i * np + k] = par(&c, v, i, k); /* vect_to_params */
+        for (int a = 0; a < nd; ++a) {
+          double d = cur[i * np + 2 + a] - coords[i * nd + a];
+          d2 += d * d;
+        }
+        if (!(d2 < p->max_shift * p->max_shift)) moved = 1;     /* refine.py:384 */
+      }
+      if (!moved) break;
+      for (int i = 0; i < n; ++i)
+        for (int a = 0; a < nd; ++a) coords[i * nd + a] = cur[i * np + 2 + a];
+    }
+    if (status == CTR_STATUS_OK && rms > p->max_rms_dev) status = CTR_STATUS_RMS_DEV; /* refine.py:391 */
+    b->status[cl] = status;
+    if (status == CTR_STATUS_OK) {
+      memcpy(pout, cur, sizeof(double) * (size_t)n * np);
+      b->cost[cl] = rms;
+    }
+    (void)nv;
+    free(cur);
+    free(coords);
+  }
+}
+
+static void frame_max(const ctr_batch* b, int nd, double* fmax) {
+  size_t felems = 1;
+  for (int a = 0; a < nd; ++a) felems *= (size_t)b->shape[a];
+  for (int64_t f = 0; f < b->n_frames; ++f) {
+    const char* base = (const char*)b->frames + (size_t)f * felems * dtype_size(b->frame_dtype);
+    double m = -INFINITY;
+    for (size_t i = 0; i < felems; ++i) {
+      double x = pixel(base, b->frame_dtype, i);
+      if (x > m || x != x) m = x; /* numpy max propagates NaN */
+      if (m != m) break;
+    }
+    fmax[f] = m;
+  }
+}
+
+int ctro_refine_batch(const ctr_problem* p, const ctr_batch* b, int n_threads) {
+  double* fmax = malloc(sizeof(double) * (size_t)(b->n_frames > 0 ? b->n_frames : 1));
+  if (p->ndim < 2 || p->ndim > 3 || p->max_iter < 1 || p->fit_function != CTR_FIT_GAUSS) { free(fmax); return CTR_ERR_INVALID; }
+  frame_max(b, p->ndim, fmax);
+  if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads)
+  for (int64_t cl = 0; cl < b->n_clusters; ++cl) refine_one(p, b, cl, fmax);
+  free(fmax);
+  return CTR_OK;
+}
+
+/* Known answer: objective F and its gradient in the reference's normalisation
+ * (fitfunc.py:436-487) at the packed start vector of cluster `cl`, first-round
+ * window.  vect/grad: [nv]; bounds: [nv][2] (compute_bounds layout). */
+int ctro_objective(const ctr_problem* p, const ctr_batch* b, int64_t cl, double* F,
+                   double* vect, double* grad, double* bounds, int32_t* origin,
+                   int32_t* wshape, int64_t* P_out) {
+  const int32_t f0 = b->feat_offset[cl], f1 = b->feat_offset[cl + 1];
+  const int n = f1 - f0, np = p->n_params, nd = p->ndim;
+  const double* params = b->params + (size_t)f0 * np;
+  ctx_t c;
+  size_t felems = 1;
+  double lo[MAXV], hi[MAXV], S;
+  long P;
+  double* fmax = malloc(sizeof(double) * (size_t)b->n_frames);
+  double* coords = malloc(sizeof(double) * (size_t)n * nd);
+  double* A;
+  c.p = p; c.b = b;
+  if (make_layout(p, n, &c.L) > MAXV) { free(fmax); free(coords); return -1; }
+  frame_max(b, nd, fmax);
+  for (int a = 0; a < nd; ++a) felems *= (size_t)b->shape[a];
+  c.frame = (const char*)b->frames + (size_t)b->frame_index[cl] * felems * dtype_size(b->frame_dtype);
+  c.n_cons = 0;
+  c.pconst = params;
+  for (int i = 0; i < n; ++i)
+    for (int a = 0; a < nd; ++a) coords[i * nd + a] = params[i * np + 2 + a];
+  if (!window(nd, b->shape, p->radius, coords, n, c.origin, c.wshape)) { free(fmax); free(coords); return -2; }
+  c.mcoords = coords;
+  pack_start(&c, params, b->low + (size_t)f0 * np, b->high + (size_t)f0 * np, vect, lo, hi);
+  A = malloc(sizeof(double) * c.L.nv * c.L.nv);
+  eval_cluster(&c, vect, &S, grad, A, &P);
+  {
+    const double fm = fmax[b->frame_index[cl]];
+    const double norm = fm * fm / p->residual_factor;
+    *F = (S / (double)P) / norm;
+    for (int i = 0; i < c.L.nv; ++i) {
+      grad[i] = 2. * grad[i] / (double)P / norm;
+      bounds[2 * i] = lo[i];
+      bounds[2 * i + 1] = hi[i];
+    }
+  }
+  for (int a = 0; a < nd; ++a) { origin[a] = c.origin[a]; wshape[a] = c.wshape[a]; }
+  *P_out = P;
+  free(A); free(fmax); free(coords);
+  return c.L.nv;
+}
