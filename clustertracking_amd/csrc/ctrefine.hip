@@ -1,0 +1,1391 @@
+// ctrefine.hip -- MI355X (gfx950) cluster-refinement engine behind include/ctrefine.h.
+//
+// One wavefront (64 lanes) fits one cluster, start to finish, without leaving
+// the CU: window (reference masks.py:30-68), elliptical masks (refine.py:43-51),
+// sum-of-Gaussians residual and Jacobian rows (fitfunc.py:14-118,436-487), the
+// normal equations, the bounded / equality-constrained Levenberg-Marquardt step,
+// the re-window rounds and the failure rules (refine.py:343-430).
+//
+// Data flow per solver iteration, per 64-pixel tile of the window:
+//   lane = pixel:  residual + Jacobian row  ->  LDS row tile R[64][16*NT+1] (f64)
+//   wave:          M += R^T R  with v_mfma_f64_16x16x4_f64, NT*(NT+1)/2 tiles of
+//                  the augmented matrix [J r]^T [J r] kept in registers
+// so J^T J, J^T r need no cross-lane reduction; M goes to LDS only when a step
+// is accepted.  Linear algebra (active-set reduction, Cholesky, range-space step
+// for the equality constraints) runs cooperatively on LDS.
+//
+// NT (16-column tiles of [J r]) is a template parameter; clusters are binned by
+// NT on the host (ctr_plan_create).  No CUDA paths, no fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "ctrefine.h"
+
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+constexpr int MAXC = 6;       // equality constraints per cluster
+constexpr int MAXF = 64;      // features per cluster
+constexpr int MAXNT = 8;      // 16*8 = 128 columns >= CTR_MAX_VARS + 1
+constexpr int FP = 14;        // derived per-feature constants (see fill_fpar)
+
+struct KArgs {
+  ctr_problem prob;
+  const void* frames;
+  int32_t frame_dtype;
+  int32_t n_bin;
+  int64_t shape[3];
+  int64_t frame_elems;
+  const int32_t* frame_index;
+  const int32_t* feat_offset;
+  const double* params;
+  const double* low;
+  const double* high;
+  double* params_out;
+  double* cost;
+  int32_t* status;
+  int32_t* n_rounds;
+  int32_t* n_iter;
+  const double* fmax;
+  const int32_t* order;  // cluster ids of this bin
+};
+
+__device__ __forceinline__ size_t dtype_size(int dtype) {
+  return dtype == CTR_DTYPE_U8 ? 1 : (dtype == CTR_DTYPE_U16 || dtype == CTR_DTYPE_I16) ? 2
+       : (dtype == CTR_DTYPE_I32 || dtype == CTR_DTYPE_F32) ? 4 : 8;
+}
+
+__device__ __forceinline__ double load_pixel(const void* base, int dtype, size_t i) {
+  switch (dtype) {
+    case CTR_DTYPE_U8: return (double)((const uint8_t*)base)[i];
+    case CTR_DTYPE_U16: return (double)((const uint16_t*)base)[i];
+    case CTR_DTYPE_I16: return (double)((const int16_t*)base)[i];
+    case CTR_DTYPE_I32: return (double)((const int32_t*)base)[i];
+    case CTR_DTYPE_F32: return (double)((const float*)base)[i];
+    default: return ((const double*)base)[i];
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+__device__ __forceinline__ double wave_max(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o));
+  return x;
+}
+__device__ __forceinline__ double bcast0(double x) { return __shfl(x, 0); }
+
+__device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
+
+struct Layout {
+  int n, nv;
+  int var_of[CTR_MAX_PARAMS];
+  int per_feat[CTR_MAX_PARAMS];
+};
+
+// vect_from_params layout with groups=None (fitfunc.py:207-263)
+__device__ __forceinline__ void make_layout(const ctr_problem& p, int n, Layout& L) {
+  int nv = 0;
+  L.n = n;
+#pragma unroll
+  for (int k = 0; k < CTR_MAX_PARAMS; ++k) {
+    int m = k < p.n_params ? p.modes[k] : CTR_MODE_CONST;
+    if (m == CTR_MODE_CONST) { L.var_of[k] = -1; L.per_feat[k] = 0; }
+    else if (m == CTR_MODE_VAR) { L.var_of[k] = nv; L.per_feat[k] = 1; nv += n; }
+    else { L.var_of[k] = nv; L.per_feat[k] = 0; nv += 1; }
+  }
+  L.nv = nv;
+}
+
+// LDS carve-up (doubles unless noted)
+template <int NT>
+struct Smem {
+  static constexpr int NVP = 16 * NT;
+  static constexpr int RS = NVP + 1;          // row stride: conflict-free row writes
+  static constexpr int NTILE = NT * (NT + 1) / 2;
+  static constexpr int NF = NVP < MAXF ? NVP : MAXF;  // features this bin can hold
+  static constexpr int NVC = NVP < 32 ? NVP : 32;     // constrained clusters have <= 29 variables
+  static constexpr int o_rows = 0;                     // 64*RS, also the packed H workspace
+  static constexpr int o_M = o_rows + WAVE * RS;       // packed lower triangle of [J r]^T [J r]
+  static constexpr int o_v = o_M + NVP * (NVP + 1) / 2;
+  static constexpr int o_vt = o_v + NVP;
+  static constexpr int o_v0 = o_vt + NVP;
+  static constexpr int o_lo = o_v0 + NVP;
+  static constexpr int o_hi = o_lo + NVP;
+  static constexpr int o_dl = o_hi + NVP;
+  static constexpr int o_w = o_dl + NVP;
+  static constexpr int o_cur = o_w + NVP;              // [NF][CTR_MAX_PARAMS] params after the latest round
+  static constexpr int o_mco = o_cur + NF * CTR_MAX_PARAMS;  // [NF][3] mask centres
+  static constexpr int o_fpar = o_mco + NF * 3;        // [NF][FP] derived constants of the trial point
+  static constexpr int o_Cj = o_fpar + NF * FP;        // [MAXC][NVC]
+  static constexpr int o_Cjt = o_Cj + MAXC * NVC;
+  static constexpr int o_Y = o_Cjt + MAXC * NVC;
+  static constexpr int o_small = o_Y + MAXC * NVC;     // cv[6] cvt[6] mult[6] rhs[6] Sc[36]
+  static constexpr int o_fr = o_small + 64;            // NVP ints (as NVP/2 doubles)
+  static constexpr int total = o_fr + NVP / 2 + 2;
+  static constexpr size_t bytes = (size_t)total * sizeof(double);
+};
+
+// ---- masks (refine.py:43-44) --------------------------------------------------
+
+template <int ND>
+__device__ __noinline__ bool in_mask_exact(const int* idx, const double* rel, const int32_t* radius) {
+#pragma clang fp contract(off)
+  double s = 0.;
+#pragma unroll
+  for (int a = 0; a < ND; ++a) {
+    double t = ((double)idx[a] - rel[a]) / (double)radius[a];
+    double t2 = t * t;
+    s = s + t2;
+  }
+  return s <= 1.;
+}
+
+// Cheap test first; the IEEE-division form only where the two could disagree.
+template <int ND>
+__device__ __forceinline__ bool in_mask(const int* idx, const double* rel, const double* inv_r2,
+                                        const int32_t* radius) {
+  double s = 0.;
+#pragma unroll
+  for (int a = 0; a < ND; ++a) {
+    double d = (double)idx[a] - rel[a];
+    s += d * d * inv_r2[a];
+  }
+  if (fabs(s - 1.) > 1e-9) return s < 1.;
+  return in_mask_exact<ND>(idx, rel, radius);
+}
+
+// masks.py:42-68; uniform across the wave (every lane computes the same box)
+template <int ND>
+__device__ bool window_of(const KArgs& k, const double* mco, int n, int* origin, int* wshape) {
+  long lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  bool any = false;
+  for (int i = 0; i < n; ++i) {
+    long ci[3];
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < ND; ++a) {
+      ci[a] = (long)rint(mco[i * 3 + a]);  // round half to even (masks.py:54)
+      if (!(ci[a] >= -(long)k.prob.radius[a] && ci[a] < (long)k.shape[a] + k.prob.radius[a])) ok = false;
+    }
+    if (!ok) continue;
+#pragma unroll
+    for (int a = 0; a < ND; ++a) {
+      if (!any || ci[a] < lo[a]) lo[a] = ci[a];
+      if (!any || ci[a] > hi[a]) hi[a] = ci[a];
+    }
+    any = true;
+  }
+  if (!any) return false;
+#pragma unroll
+  for (int a = 0; a < ND; ++a) {
+    long l = lo[a] - k.prob.radius[a], u = hi[a] + k.prob.radius[a] + 1;
+    if (l < 0) l = 0;
+    if (u > k.shape[a]) u = k.shape[a];
+    origin[a] = (int)l;
+    wshape[a] = (int)(u - l);
+  }
+  return true;
+}
+
+// ---- per-cluster state shared by the device routines ---------------------------
+
+template <int ND, bool ISO, int NT>
+struct Ctx {
+  using S = Smem<NT>;
+  static constexpr int NP = 2 + ND + (ISO ? 1 : ND);
+  static constexpr int NSZ = ISO ? 1 : ND;
+  double* sm;
+  Layout L;
+  int lane;
+  int origin[3], wshape[3];
+  const void* frame;
+  int n_cons;
+
+  __device__ __forceinline__ double* rows() { return sm + S::o_rows; }
+  __device__ __forceinline__ double* M() { return sm + S::o_M; }
+  __device__ __forceinline__ double* cur() { return sm + S::o_cur; }
+  __device__ __forceinline__ double* mco() { return sm + S::o_mco; }
+  __device__ __forceinline__ double* fpar() { return sm + S::o_fpar; }
+
+  // parameter k of feature i at vector vv (vect_to_params, fitfunc.py:266-315)
+  __device__ __forceinline__ double par(const double* vv, int i, int k) {
+    int b = L.var_of[k];
+    if (b < 0) return cur()[i * CTR_MAX_PARAMS + k];
+    return vv[b + (L.per_feat[k] ? i : 0)];
+  }
+};
+
+// Derived constants of feature i at the trial vector: lanes i < n, then sync.
+//   [0] signal  [1..3] centre  [4..6] 1/size_a^2  [7..9] 2/size_a^2  [10..12] -2/size_a^3
+template <int ND, bool ISO, int NT>
+__device__ void fill_fpar(Ctx<ND, ISO, NT>& c, const double* vv) {
+  constexpr int NP = Ctx<ND, ISO, NT>::NP;
+  for (int i = c.lane; i < c.L.n; i += WAVE) {
+    double* f = c.fpar() + i * FP;
+    f[0] = c.par(vv, i, 1);
+#pragma unroll
+    for (int a = 0; a < ND; ++a) {
+      f[1 + a] = c.par(vv, i, 2 + a);
+      double sz = c.par(vv, i, ISO ? 2 + ND : 2 + ND + a);
+      double s2 = sz * sz;
+      f[4 + a] = 1. / s2;
+      f[7 + a] = 2. / s2;
+      f[10 + a] = -2. / (s2 * sz);
+    }
+  }
+  (void)NP;
+  __syncthreads();
+}
+
+// One pass over the window at vector vv: acc = [J r]^T [J r] (registers),
+// S = sum r^2, P = pixels in the union mask.  (fitfunc.py:436-487)
+template <int ND, bool ISO, int NT>
+__device__ void eval(const KArgs& k, Ctx<ND, ISO, NT>& c, const double* vv,
+                     v4d (&acc)[Smem<NT>::NTILE], double& S_out, int& P_out) {
+  using SM = Smem<NT>;
+  constexpr int NP = Ctx<ND, ISO, NT>::NP;
+  constexpr int NSZ = Ctx<ND, ISO, NT>::NSZ;
+  const int lane = c.lane, n = c.L.n, nv = c.L.nv;
+  const int w1 = c.wshape[ND - 2], w2 = c.wshape[ND - 1];
+  const int npix = (ND == 3 ? c.wshape[0] : 1) * w1 * w2;
+  const int bgvar = c.L.var_of[0];
+  double inv_r2[3];
+#pragma unroll
+  for (int a = 0; a < ND; ++a) inv_r2[a] = 1. / ((double)k.prob.radius[a] * (double)k.prob.radius[a]);
+  fill_fpar(c, vv);
+  const double bg = c.par(vv, 0, 0);
+#pragma unroll
+  for (int t = 0; t < SM::NTILE; ++t) acc[t] = v4d{0., 0., 0., 0.};
+  double Sloc = 0.;
+  int P = 0;
+  double* row = c.rows() + lane * SM::RS;
+  const double* fpar = c.fpar();
+  const double* mco = c.mco();
+
+  for (int base = 0; base < npix; base += WAVE) {
+    const int q = base + lane;
+    const bool valid = q < npix;
+    int idx[3];
+    size_t off;
+    {
+      int x = q % w2, t = q / w2;
+      if (ND == 3) {
+        int y = t % w1, z = t / w1;
+        idx[0] = z; idx[1] = y; idx[2] = x;
+        off = ((size_t)(z + c.origin[0]) * k.shape[1] + (y + c.origin[1])) * k.shape[2] + (x + c.origin[2]);
+      } else {
+        idx[0] = t; idx[1] = x;
+        off = (size_t)(t + c.origin[0]) * k.shape[1] + (x + c.origin[1]);
+      }
+    }
+    bool any = false;
+    double res = 0.;
+    double shared[CTR_MAX_PARAMS];
+#pragma unroll
+    for (int kk = 0; kk < CTR_MAX_PARAMS; ++kk) shared[kk] = 0.;
+    for (int i = 0; i < n; ++i) {
+      double d[1 + ND + NSZ];
+#pragma unroll
+      for (int t = 0; t < 1 + ND + NSZ; ++t) d[t] = 0.;
+      bool in = false;
+      if (valid) {
+        double rel[3];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) rel[a] = mco[i * 3 + a] - (double)c.origin[a];
+        in = in_mask<ND>(idx, rel, inv_r2, k.prob.radius);
+      }
+      if (in) {
+        const double* f = fpar + i * FP;
+        if (!any) {
+          any = true;
+          res = load_pixel(c.frame, k.frame_dtype, off) - bg;
+        }
+        double r2 = 0., dd[3];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+          dd[a] = (double)(idx[a] + c.origin[a]) - f[1 + a];
+          r2 += dd[a] * dd[a] * f[4 + a];
+        }
+        const double gv = exp(-0.5 * ND * r2);  // fitfunc.py:112-118
+        const double sig = f[0];
+        const double sdg = sig * (0.5 * ND) * gv;  // -signal * dg/dr2
+        res -= sig * gv;
+        d[0] = -gv;
+        double q2 = 0.;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+          d[1 + a] = sdg * (-dd[a] * f[7 + a]);           // dr2/dc_a = 2 (c_a - x_a) / size_a^2
+          if (ISO) q2 += dd[a] * dd[a];
+          else d[1 + ND + a] = sdg * (dd[a] * dd[a] * f[10 + a]);  // dr2/dsize_a = -2 (x_a-c_a)^2 / size_a^3
+        }
+        if (ISO) d[1 + ND] = sdg * (q2 * f[10]);
+      }
+#pragma unroll
+      for (int kk = 1; kk < NP; ++kk) {
+        const int b = c.L.var_of[kk];
+        if (b < 0) continue;
+        if (c.L.per_feat[kk]) row[b + i] = d[kk - 1];
+        else shared[kk] += d[kk - 1];
+      }
+    }
+    const bool good = any && (res == res);  // nansum (fitfunc.py:449,483)
+#pragma unroll
+    for (int kk = 1; kk < NP; ++kk) {
+      const int b = c.L.var_of[kk];
+      if (b >= 0 && !c.L.per_feat[kk]) row[b] = shared[kk];
+    }
+    if (bgvar >= 0) row[bgvar] = good ? -1. : 0.;
+    row[nv] = good ? res : 0.;
+    if (any && !good) {
+      for (int j = 0; j < nv; ++j) row[j] = 0.;
+    }
+    const unsigned long long bal = __ballot(any);
+    P += __popcll(bal);
+    if (good) Sloc += res * res;
+    __syncthreads();
+    if (bal != 0ull) {
+      const int kr = lane >> 4, cc = lane & 15;
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {
+        const double* rp = c.rows() + (4 * s + kr) * SM::RS + cc;
+        double val[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) val[t] = rp[16 * t];
+        int tt = 0;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+          for (int tj = 0; tj <= ti; ++tj) {
+            acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[ti], val[tj], acc[tt], 0, 0, 0);
+            ++tt;
+          }
+      }
+    }
+    __syncthreads();
+  }
+  S_out = wave_sum(Sloc);
+  P_out = P;
+}
+
+// acc (registers) -> packed lower triangle in LDS.  D layout of v_mfma_f64_16x16x4:
+// col = lane & 15, row = (lane >> 4) + 4 * reg.
+template <int NT>
+__device__ void store_M(double* Mp, const v4d (&acc)[Smem<NT>::NTILE], int lane) {
+  const int cc = lane & 15, r0 = lane >> 4;
+  int tt = 0;
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+    for (int tj = 0; tj <= ti; ++tj) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = 16 * ti + r0 + 4 * r, gj = 16 * tj + cc;
+        if (gi >= gj) Mp[tri(gi) + gj] = acc[tt][r];
+      }
+      ++tt;
+    }
+  __syncthreads();
+}
+
+__device__ __forceinline__ double Msym(const double* Mp, int i, int j) {
+  return i >= j ? Mp[tri(i) + j] : Mp[tri(j) + i];
+}
+
+// ---- cooperative dense algebra on a packed lower-triangular matrix in LDS ------
+
+// in-place Cholesky; lane owns rows lane, lane+64.  Uniform return.
+__device__ bool chol_factor(double* Hp, int nf, int lane) {
+  for (int j = 0; j < nf; ++j) {
+    for (int i = lane; i < nf; i += WAVE) {
+      if (i < j) continue;
+      double s = Hp[tri(i) + j];
+      const double* ri = Hp + tri(i);
+      const double* rj = Hp + tri(j);
+      for (int kk = 0; kk < j; ++kk) s -= ri[kk] * rj[kk];
+      Hp[tri(i) + j] = s;
+    }
+    __syncthreads();
+    const double d = Hp[tri(j) + j];
+    if (!(d > 0.) || !isfinite(d)) return false;
+    const double sd = sqrt(d);
+    for (int i = lane; i < nf; i += WAVE) {
+      if (i > j) Hp[tri(i) + j] /= sd;
+      else if (i == j) Hp[tri(j) + j] = sd;
+    }
+    __syncthreads();
+  }
+  return true;
+}
+
+// solve L L^T x = b in place for nrhs right-hand sides x[r*ldx + i]
+__device__ void chol_solve(const double* Lp, int nf, double* x, int nrhs, int ldx, int lane) {
+  for (int j = 0; j < nf; ++j) {
+    const double ljj = Lp[tri(j) + j];
+    for (int r = 0; r < nrhs; ++r) {
+      const double yj = x[r * ldx + j] / ljj;
+      for (int i = lane; i < nf; i += WAVE)
+        if (i > j) x[r * ldx + i] -= Lp[tri(i) + j] * yj;
+    }
+    __syncthreads();
+    if (lane == 0)
+      for (int r = 0; r < nrhs; ++r) x[r * ldx + j] /= ljj;
+    __syncthreads();
+  }
+  for (int j = nf - 1; j >= 0; --j) {
+    const double ljj = Lp[tri(j) + j];
+    for (int r = 0; r < nrhs; ++r) {
+      const double xj = x[r * ldx + j] / ljj;
+      for (int i = lane; i < j; i += WAVE) x[r * ldx + i] -= Lp[tri(j) + i] * xj;
+    }
+    __syncthreads();
+    if (lane == 0)
+      for (int r = 0; r < nrhs; ++r) x[r * ldx + j] /= ljj;
+    __syncthreads();
+  }
+}
+
+// ---- equality constraints (constraints.py:59-137) -------------------------------
+
+__device__ __forceinline__ int n_constraints(const ctr_problem& p, int n) {
+  switch (p.constraint_kind) {
+    case CTR_CONS_DIMER: return n == 2 ? 1 : 0;
+    case CTR_CONS_TRIMER: return n == 3 ? 3 : 0;
+    case CTR_CONS_TETRAMER: return n == 4 ? (p.ndim == 2 ? 4 : 6) : 0;
+    default: return 0;
+  }
+}
+
+// cv[m], Cj[m][ld] at vector vv; every lane computes the pair distances, lane r
+// (by rank of its pair) writes row r.
+template <int ND, bool ISO, int NT>
+__device__ void eval_constraints(const KArgs& k, Ctx<ND, ISO, NT>& c, const double* vv,
+                                 double* cv, double* Cj, int ld) {
+  const int m = c.n_cons;
+  if (m == 0) return;
+  const int P0[6] = {0, 1, 0, 1, 0, 2}, P1[6] = {1, 2, 2, 3, 3, 3};
+  const int npairs = k.prob.constraint_kind == CTR_CONS_DIMER ? 1
+                   : k.prob.constraint_kind == CTR_CONS_TRIMER ? 3 : 6;
+  double d2[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    d2[q] = 0.;
+    if (q < npairs) {
+#pragma unroll
+      for (int a = 0; a < ND; ++a) {
+        double t = (c.par(vv, P0[q], 2 + a) - c.par(vv, P1[q], 2 + a)) / k.prob.constraint_dist[a];
+        d2[q] += t * t;
+      }
+    }
+  }
+  for (int e = c.lane; e < m * ld; e += WAVE) Cj[e] = 0.;
+  __syncthreads();
+  const int q = c.lane;
+  if (q < npairs) {
+    int rank = q;
+    if (k.prob.constraint_kind == CTR_CONS_TETRAMER && ND == 2) {
+      rank = 0;  // stable rank among the 6 squared distances (constraints.py:112)
+#pragma unroll
+      for (int p = 0; p < 6; ++p) rank += (d2[p] < d2[q] || (d2[p] == d2[q] && p < q)) ? 1 : 0;
+    }
+    if (rank < m) {
+      double mine = 0.;
+#pragma unroll
+      for (int p = 0; p < 6; ++p) if (p == q) mine = d2[p];
+      cv[rank] = 1. - mine;
+      const int i0 = P0[q], i1 = P1[q];
+#pragma unroll
+      for (int a = 0; a < ND; ++a) {
+        const int kk = 2 + a, b = c.L.var_of[kk];
+        if (b < 0) continue;
+        const double da = k.prob.constraint_dist[a];
+        const double t = -2. * (c.par(vv, i0, kk) - c.par(vv, i1, kk)) / (da * da);
+        Cj[rank * ld + b + (c.L.per_feat[kk] ? i0 : 0)] += t;
+        Cj[rank * ld + b + (c.L.per_feat[kk] ? i1 : 0)] -= t;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ---- bounded (+ equality constrained) Levenberg-Marquardt ----------------------
+
+struct SolveOut { double S; int P; int iters; bool ok; };
+
+template <int ND, bool ISO, int NT>
+__device__ SolveOut solve(const KArgs& k, Ctx<ND, ISO, NT>& c) {
+  using SM = Smem<NT>;
+  double* sm = c.sm;
+  double *v = sm + SM::o_v, *vt = sm + SM::o_vt, *v0 = sm + SM::o_v0, *lo = sm + SM::o_lo,
+         *hi = sm + SM::o_hi, *dl = sm + SM::o_dl, *w = sm + SM::o_w, *Mp = sm + SM::o_M,
+         *Hp = sm + SM::o_rows;
+  double *Cj = sm + SM::o_Cj, *Cjt = sm + SM::o_Cjt, *Y = sm + SM::o_Y;
+  double *cv = sm + SM::o_small, *cvt = cv + 6, *mult = cv + 12, *Sc = cv + 24, *flag = cv + 60;
+  int* fr = (int*)(sm + SM::o_fr);
+  constexpr int LDC = SM::NVC;
+  const int lane = c.lane, nv = c.L.nv, m = c.n_cons;
+  const int maxiter = k.prob.solver_maxiter > 0 ? k.prob.solver_maxiter : 100;
+  const double xtol = k.prob.xtol > 0 ? k.prob.xtol : 1e-9;
+  const double ftol = k.prob.ftol > 0 ? k.prob.ftol : 1e-14;
+  SolveOut out{NAN, 0, 0, false};
+  v4d acc[SM::NTILE];
+
+  bool infeasible = false;
+  for (int i = lane; i < nv; i += WAVE) {
+    if (lo[i] > hi[i]) infeasible = true;
+    double x = v0[i];
+    v[i] = x < lo[i] ? lo[i] : (x > hi[i] ? hi[i] : x);
+  }
+  if (lane < MAXC) mult[lane] = 0.;
+  __syncthreads();
+  if (__ballot(infeasible) != 0ull) return out;
+
+  double S;
+  int P;
+  eval(k, c, v, acc, S, P);
+  out.P = P;
+  if (P == 0 || !isfinite(S)) return out;
+  store_M<NT>(Mp, acc, lane);
+  eval_constraints(k, c, v, cv, Cj, LDC);
+
+  double mu = 1e-3, nu = 2., sigma = 0.;
+  bool last_accepted = true;
+
+  for (int it = 0; it < maxiter; ++it) {
+    out.iters = it + 1;
+    // active set: fixed if at a bound and the Lagrangian gradient pushes outward
+    int nf = 0;
+    for (int b0 = 0; b0 < nv; b0 += WAVE) {
+      const int i = b0 + lane;
+      bool fre = false;
+      if (i < nv) {
+        double gl = Mp[tri(nv) + i];
+        for (int r = 0; r < m; ++r) gl += Cj[r * LDC + i] * mult[r];
+        const bool fixed = (lo[i] == hi[i]) || (v[i] <= lo[i] && gl > 0.) || (v[i] >= hi[i] && gl < 0.);
+        fre = !fixed;
+      }
+      const unsigned long long bal = __ballot(fre);
+      if (fre) fr[nf + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+      nf += __popcll(bal);
+    }
+    __syncthreads();
+    if (nf == 0) { out.ok = true; break; }
+    // H = A_FF + mu * diag(A_FF)
+    for (int e = lane; e < tri(nf); e += WAVE) {
+      int a = (int)((sqrt(8. * e + 1.) - 1.) * 0.5);
+      while (tri(a + 1) <= e) ++a;
+      while (tri(a) > e) --a;
+      const int b = e - tri(a);
+      double h = Msym(Mp, fr[a], fr[b]);
+      if (a == b) h += mu * (h > 1e-300 ? h : 1.);
+      Hp[e] = h;
+    }
+    __syncthreads();
+    if (!chol_factor(Hp, nf, lane)) {
+      mu *= nu; nu *= 2.; last_accepted = false;
+      if (mu > 1e30) break;
+      continue;
+    }
+    // w = H^-1 g_F ; Y_r = H^-1 C_F,r^T
+    for (int a = lane; a < nf; a += WAVE) {
+      w[a] = Mp[tri(nv) + fr[a]];
+      for (int r = 0; r < m; ++r) Y[r * LDC + a] = Cj[r * LDC + fr[a]];
+    }
+    __syncthreads();
+    chol_solve(Hp, nf, w, 1, 0, lane);
+    if (m) chol_solve(Hp, nf, Y, m, LDC, lane);
+    bool bad_schur = false;
+    if (m) {
+      // (C H^-1 C^T) mult = c - C H^-1 g   (range-space form of the KKT step)
+      if (lane < m * m) {
+        const int r = lane / m, s = lane % m;
+        double t = 0.;
+        for (int a = 0; a < nf; ++a) t += Cj[r * LDC + fr[a]] * Y[s * LDC + a];
+        Sc[r * MAXC + s] = t;
+      }
+      if (lane < m) {
+        double t = cv[lane];
+        for (int a = 0; a < nf; ++a) t -= Cj[lane * LDC + fr[a]] * w[a];
+        mult[lane] = t;
+      }
+      __syncthreads();
+      if (lane == 0) {
+        // tiny dense Cholesky + solve, serial (m <= 6)
+        double tr = 0.;
+        for (int r = 0; r < m; ++r) tr += Sc[r * MAXC + r];
+        for (int r = 0; r < m; ++r) Sc[r * MAXC + r] += 1e-14 * tr + 1e-300;
+        bool okc = true;
+        for (int j = 0; j < m && okc; ++j) {
+          double d = Sc[j * MAXC + j];
+          for (int q = 0; q < j; ++q) d -= Sc[j * MAXC + q] * Sc[j * MAXC + q];
+          if (!(d > 0.) || !isfinite(d)) { okc = false; break; }
+          d = sqrt(d);
+          Sc[j * MAXC + j] = d;
+          for (int i = j + 1; i < m; ++i) {
+            double s = Sc[i * MAXC + j];
+            for (int q = 0; q < j; ++q) s -= Sc[i * MAXC + q] * Sc[j * MAXC + q];
+            Sc[i * MAXC + j] = s / d;
+          }
+        }
+        if (okc) {
+          for (int i = 0; i < m; ++i) {
+            double s = mult[i];
+            for (int q = 0; q < i; ++q) s -= Sc[i * MAXC + q] * mult[q];
+            mult[i] = s / Sc[i * MAXC + i];
+          }
+          for (int i = m - 1; i >= 0; --i) {
+            double s = mult[i];
+            for (int q = i + 1; q < m; ++q) s -= Sc[q * MAXC + i] * mult[q];
+            mult[i] = s / Sc[i * MAXC + i];
+          }
+        } else {
+          for (int i = 0; i < m; ++i) mult[i] = 0.;
+        }
+        flag[0] = okc ? 1. : 0.;
+      }
+      __syncthreads();
+      bad_schur = flag[0] == 0.;
+    }
+    if (bad_schur) {
+      mu *= nu; nu *= 2.; last_accepted = false;
+      if (mu > 1e30) break;
+      continue;
+    }
+    // step on the free variables, projected onto the box
+    for (int i = lane; i < nv; i += WAVE) dl[i] = 0.;
+    __syncthreads();
+    for (int a = lane; a < nf; a += WAVE) {
+      double t = w[a];
+      for (int r = 0; r < m; ++r) t += Y[r * LDC + a] * mult[r];
+      dl[fr[a]] = -t;
+    }
+    __syncthreads();
+    double stepmax = 0.;
+    for (int i = lane; i < nv; i += WAVE) {
+      double t = v[i] + dl[i];
+      t = t < lo[i] ? lo[i] : (t > hi[i] ? hi[i] : t);
+      vt[i] = t;
+      const double d = t - v[i];
+      dl[i] = d;
+      stepmax = fmax(stepmax, fabs(d) / (fabs(v[i]) + 1.));
+    }
+    __syncthreads();
+    stepmax = wave_max(stepmax);
+    double part = 0.;
+    for (int i = lane; i < nv; i += WAVE) {
+      double t = 0.;
+      for (int j = 0; j < nv; ++j) t += Msym(Mp, i, j) * dl[j];
+      part += dl[i] * (Mp[tri(nv) + i] + 0.5 * t);
+    }
+    double pred = -wave_sum(part);
+    double cn = 0., cn_lin = 0.;
+    if (m) {
+      double mmax = 0.;
+      for (int r = 0; r < m; ++r) {
+        double t = cv[r];
+        for (int i = 0; i < nv; ++i) t += Cj[r * LDC + i] * dl[i];
+        cn += fabs(cv[r]);
+        cn_lin += fabs(t);
+        mmax = fmax(mmax, fabs(mult[r]));
+      }
+      if (sigma < 2. * mmax) sigma = 2. * mmax;
+      pred += sigma * (cn - cn_lin);
+    }
+    pred = bcast0(pred);
+    stepmax = bcast0(stepmax);
+    const bool feasible = (m == 0) || (cn <= 1e-10);
+    if (feasible && ((last_accepted && stepmax <= xtol) || pred <= ftol * (0.5 * S) + 1e-300)) {
+      out.ok = true;
+      break;
+    }
+    double St;
+    int Pt;
+    eval(k, c, vt, acc, St, Pt);
+    eval_constraints(k, c, vt, cvt, Cjt, LDC);
+    double cnt = 0.;
+    for (int r = 0; r < m; ++r) cnt += fabs(cvt[r]);
+    double act = 0.5 * (S - St) + (m ? sigma * (cn - cnt) : 0.);
+    act = bcast0(act);
+    if (isfinite(St) && pred > 0. && act > 0.) {
+      const double rho = act / pred, t = 2. * rho - 1.;
+      const double f = 1. - t * t * t;
+      mu *= f > 1. / 3. ? f : 1. / 3.;
+      nu = 2.;
+      for (int i = lane; i < nv; i += WAVE) v[i] = vt[i];
+      for (int e = lane; e < m * LDC; e += WAVE) Cj[e] = Cjt[e];
+      if (lane < m) cv[lane] = cvt[lane];
+      store_M<NT>(Mp, acc, lane);  // syncs
+      S = St;
+      last_accepted = true;
+    } else {
+      mu *= nu;
+      nu *= 2.;
+      last_accepted = false;
+      if (mu > 1e30) break;
+    }
+  }
+  out.S = S;
+  return out;
+}
+
+// ---- the kernel: one wave per cluster --------------------------------------------
+
+template <int ND, bool ISO, int NT>
+__global__ void __launch_bounds__(WAVE) refine_kernel(const KArgs k) {
+  using SM = Smem<NT>;
+  constexpr int NP = 2 + ND + (ISO ? 1 : ND);
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x;
+  const int cl = k.order[blockIdx.x];
+  const int f0 = k.feat_offset[cl], n = k.feat_offset[cl + 1] - f0;
+  const double* params = k.params + (size_t)f0 * NP;
+  double* pout = k.params_out + (size_t)f0 * NP;
+
+  Ctx<ND, ISO, NT> c;
+  c.sm = smem;
+  c.lane = lane;
+  make_layout(k.prob, n, c.L);
+  c.n_cons = n_constraints(k.prob, n);
+  c.frame = (const char*)k.frames + (size_t)k.frame_index[cl] * k.frame_elems * dtype_size(k.frame_dtype);
+
+  // params_out starts as a copy of params; failures leave it that way (refine.py:408-418)
+  bool finite = true;
+  for (int e = lane; e < n * NP; e += WAVE) {
+    const double x = params[e];
+    pout[e] = x;
+    smem[SM::o_cur + (e / NP) * CTR_MAX_PARAMS + (e % NP)] = x;
+    if (!isfinite(x)) finite = false;
+  }
+  int status = CTR_STATUS_OK, rounds = 0, iters = 0;
+  double rms = NAN;
+  if (__ballot(!finite) != 0ull) status = CTR_STATUS_NONFINITE;  // refine.py:356-357
+  if (n <= 0) status = CTR_STATUS_OUT_OF_BOUNDS;
+
+  if (status == CTR_STATUS_OK) {
+    // zero the row tile once: columns > nv are never written again
+    for (int e = lane; e < WAVE * SM::RS; e += WAVE) smem[SM::o_rows + e] = 0.;
+    for (int e = lane; e < n * 3; e += WAVE) {
+      const int i = e / 3, a = e % 3;
+      smem[SM::o_mco + e] = a < ND ? params[i * NP + 2 + a] : 0.;
+    }
+    // start vector (mean for shared parameters, refine.py:361) and packed
+    // bounds (loosest for shared parameters, fitfunc.py:554-557)
+    const double* low = k.low + (size_t)f0 * NP;
+    const double* high = k.high + (size_t)f0 * NP;
+    for (int kk = 0; kk < NP; ++kk) {
+      const int b = c.L.var_of[kk];
+      if (b < 0) continue;
+      if (c.L.per_feat[kk]) {
+        for (int i = lane; i < n; i += WAVE) {
+          smem[SM::o_v0 + b + i] = params[i * NP + kk];
+          smem[SM::o_lo + b + i] = low[i * NP + kk];
+          smem[SM::o_hi + b + i] = high[i * NP + kk];
+        }
+      } else if (lane == 0) {
+        double s = 0., l = INFINITY, h = -INFINITY;
+        for (int i = 0; i < n; ++i) {
+          s += params[i * NP + kk];
+          l = fmin(l, low[i * NP + kk]);
+          h = fmax(h, high[i * NP + kk]);
+        }
+        smem[SM::o_v0 + b] = s / n;
+        smem[SM::o_lo + b] = l;
+        smem[SM::o_hi + b] = h;
+      }
+    }
+    __syncthreads();
+    const double fm = k.fmax[k.frame_index[cl]];
+    const double norm = fm * fm / k.prob.residual_factor;  // refine.py:354
+    const double* v = smem + SM::o_v;
+    double* cur = smem + SM::o_cur;
+    double* mco = smem + SM::o_mco;
+    const double ms2 = k.prob.max_shift * k.prob.max_shift;
+
+    for (int round = 0; round < k.prob.max_iter; ++round) {
+      rounds = round + 1;
+      if (!window_of<ND>(k, mco, n, c.origin, c.wshape)) {
+        status = CTR_STATUS_OUT_OF_BOUNDS;  // refine.py:33-34
+        break;
+      }
+      const SolveOut r = solve(k, c);
+      iters += r.iters;
+      if (r.P == 0) { status = CTR_STATUS_OUT_OF_BOUNDS; break; }
+      if (!r.ok) { status = CTR_STATUS_NO_CONVERGENCE; break; }  // refine.py:376-377
+      rms = sqrt(((r.S / (double)r.P) / norm) / k.prob.residual_factor);  // refine.py:379
+      // vect_to_params, then the shift test (refine.py:380-388)
+      __syncthreads();
+      bool moved = false;
+      for (int i = lane; i < n; i += WAVE) {
+        double d2 = 0.;
+#pragma unroll
+        for (int kk = 0; kk < NP; ++kk) {
+          const int b = c.L.var_of[kk];
+          if (b >= 0) cur[i * CTR_MAX_PARAMS + kk] = v[b + (c.L.per_feat[kk] ? i : 0)];
+        }
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+          const double d = cur[i * CTR_MAX_PARAMS + 2 + a] - mco[i * 3 + a];
+          d2 += d * d;
+        }
+        if (!(d2 < ms2)) moved = true;
+      }
+      const bool any_moved = __ballot(moved) != 0ull;
+      __syncthreads();
+      if (!any_moved) break;
+      for (int e = lane; e < n * 3; e += WAVE) {
+        const int i = e / 3, a = e % 3;
+        if (a < ND) mco[e] = cur[i * CTR_MAX_PARAMS + 2 + a];
+      }
+      __syncthreads();
+    }
+    if (status == CTR_STATUS_OK && rms > k.prob.max_rms_dev) status = CTR_STATUS_RMS_DEV;  // refine.py:391
+    if (status == CTR_STATUS_OK) {
+      __syncthreads();
+      for (int e = lane; e < n * NP; e += WAVE) pout[e] = cur[(e / NP) * CTR_MAX_PARAMS + (e % NP)];
+    }
+  }
+  if (lane == 0) {
+    k.status[cl] = status;
+    k.cost[cl] = status == CTR_STATUS_OK ? rms : NAN;
+    k.n_rounds[cl] = rounds;
+    k.n_iter[cl] = iters;
+  }
+}
+
+// clusters the engine cannot take (too many variables / features)
+__global__ void mark_kernel(const KArgs k, int code) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k.n_bin) return;
+  const int cl = k.order[t];
+  const int np = k.prob.n_params;
+  for (int e = k.feat_offset[cl] * np; e < k.feat_offset[cl + 1] * np; ++e) k.params_out[e] = k.params[e];
+  k.status[cl] = code;
+  k.cost[cl] = NAN;
+  k.n_rounds[cl] = 0;
+  k.n_iter[cl] = 0;
+}
+
+// ---- per-frame maximum (the norm of refine.py:354) --------------------------------
+// Streams the frame block once: 16 B per lane per load, one ordered-u64 atomicMax
+// per workgroup.  HBM-bound.
+
+__device__ __forceinline__ unsigned long long enc_f64(double x) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dec_f64(unsigned long long e) {
+  unsigned long long b = (e >> 63) ? (e & 0x7fffffffffffffffull) : ~e;
+  return __longlong_as_double((long long)b);
+}
+
+template <typename T>
+__device__ __forceinline__ double chunk_max(const T* p, size_t n, int tid, int nthreads) {
+  constexpr int V = 16 / sizeof(T);
+  double m = -INFINITY;
+  const uintptr_t addr = (uintptr_t)p;
+  size_t head = (16 - (addr & 15)) & 15;
+  head /= sizeof(T);
+  if (head > n) head = n;
+  for (size_t i = tid; i < head; i += nthreads) {
+    const double x = (double)p[i];
+    m = (x > m || x != x) ? x : m;
+  }
+  const size_t nvec = (n - head) / V;
+  const uint4* pv = (const uint4*)(p + head);
+  for (size_t i = tid; i < nvec; i += nthreads) {
+    uint4 raw = pv[i];
+    T vals[V];
+    __builtin_memcpy(vals, &raw, 16);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const double x = (double)vals[j];
+      m = (x > m || x != x) ? x : m;
+    }
+  }
+  for (size_t i = head + nvec * V + tid; i < n; i += nthreads) {
+    const double x = (double)p[i];
+    m = (x > m || x != x) ? x : m;
+  }
+  return m;
+}
+
+constexpr int FM_THREADS = 256;
+constexpr size_t FM_CHUNK_BYTES = 64 * 1024;
+
+__global__ void __launch_bounds__(FM_THREADS) frame_max_kernel(const void* frames, int dtype,
+                                                               size_t frame_elems, int chunks_per_frame,
+                                                               size_t chunk_elems,
+                                                               unsigned long long* enc) {
+  const int frame = blockIdx.x / chunks_per_frame, chunk = blockIdx.x % chunks_per_frame;
+  const size_t begin = (size_t)chunk * chunk_elems;
+  size_t n = frame_elems - begin;
+  if (n > chunk_elems) n = chunk_elems;
+  const size_t e0 = (size_t)frame * frame_elems + begin;
+  double m;
+  switch (dtype) {
+    case CTR_DTYPE_U8: m = chunk_max((const uint8_t*)frames + e0, n, threadIdx.x, FM_THREADS); break;
+    case CTR_DTYPE_U16: m = chunk_max((const uint16_t*)frames + e0, n, threadIdx.x, FM_THREADS); break;
+    case CTR_DTYPE_I16: m = chunk_max((const int16_t*)frames + e0, n, threadIdx.x, FM_THREADS); break;
+    case CTR_DTYPE_I32: m = chunk_max((const int32_t*)frames + e0, n, threadIdx.x, FM_THREADS); break;
+    case CTR_DTYPE_F32: m = chunk_max((const float*)frames + e0, n, threadIdx.x, FM_THREADS); break;
+    default: m = chunk_max((const double*)frames + e0, n, threadIdx.x, FM_THREADS); break;
+  }
+  unsigned long long e = enc_f64(m);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long other = __shfl_xor(e, o);
+    e = other > e ? other : e;
+  }
+  __shared__ unsigned long long part[FM_THREADS / WAVE];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = e;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int wv = 1; wv < FM_THREADS / WAVE; ++wv) e = part[wv] > e ? part[wv] : e;
+    atomicMax(enc + frame, e);
+  }
+}
+
+__global__ void frame_max_decode_kernel(const unsigned long long* enc, double* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = dec_f64(enc[i]);
+}
+
+// ---- host side ------------------------------------------------------------------------
+
+typedef void (*kernel_fn)(const KArgs);
+
+template <int ND, bool ISO>
+void fill_table(kernel_fn* t, size_t* bytes) {
+  t[0] = refine_kernel<ND, ISO, 1>; bytes[0] = Smem<1>::bytes;
+  t[1] = refine_kernel<ND, ISO, 2>; bytes[1] = Smem<2>::bytes;
+  t[2] = refine_kernel<ND, ISO, 3>; bytes[2] = Smem<3>::bytes;
+  t[3] = refine_kernel<ND, ISO, 4>; bytes[3] = Smem<4>::bytes;
+  t[4] = refine_kernel<ND, ISO, 5>; bytes[4] = Smem<5>::bytes;
+  t[5] = refine_kernel<ND, ISO, 6>; bytes[5] = Smem<6>::bytes;
+  t[6] = refine_kernel<ND, ISO, 7>; bytes[6] = Smem<7>::bytes;
+  t[7] = refine_kernel<ND, ISO, 8>; bytes[7] = Smem<8>::bytes;
+}
+
+std::string g_create_error;
+std::mutex g_mutex;
+
+}  // namespace
+
+struct ctr_plan {
+  ctr_problem prob;
+  int64_t n_clusters = 0;
+  int device = 0;
+  int32_t* d_order = nullptr;          // all bins back to back
+  int64_t bin_begin[MAXNT + 2] = {0};  // bins 0..MAXNT-1 by NT-1, bin MAXNT = too large
+  int64_t bin_count[MAXNT + 1] = {0};
+};
+
+struct ctr_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool ev_valid = false;
+  std::string err;
+  // grow-only device scratch
+  void* d_buf = nullptr;
+  size_t d_buf_bytes = 0;
+  unsigned long long* d_enc = nullptr;
+  double* d_fmax = nullptr;
+  int64_t fmax_cap = 0;
+  kernel_fn table[2][2][MAXNT];
+  size_t smem_bytes[2][2][MAXNT];
+  bool attr_set[2][2][MAXNT] = {};
+};
+
+namespace {
+
+int fail(ctr_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  else { std::lock_guard<std::mutex> g(g_mutex); g_create_error = msg; }
+  return code;
+}
+
+#define HIP_TRY(h, call)                                                                   \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(h, CTR_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+
+int validate(const ctr_problem* p, std::string& msg) {
+  if (!p) { msg = "null problem"; return CTR_ERR_INVALID; }
+  if (p->ndim != 2 && p->ndim != 3) { msg = "ndim must be 2 or 3"; return CTR_ERR_INVALID; }
+  if (p->fit_function != CTR_FIT_GAUSS) {
+    msg = "only the gauss fit function is implemented";
+    return (p->fit_function >= 0 && p->fit_function <= CTR_FIT_INV_SERIES) ? CTR_ERR_UNSUPPORTED : CTR_ERR_INVALID;
+  }
+  const int np = 2 + p->ndim + (p->isotropic ? 1 : p->ndim);
+  if (p->n_params != np) { msg = "n_params does not match ndim/isotropic"; return CTR_ERR_INVALID; }
+  for (int k = 0; k < np; ++k) {
+    const int m = p->modes[k];
+    if (m == CTR_MODE_GLOBAL) { msg = "param mode 'global' couples all clusters and is not supported"; return CTR_ERR_UNSUPPORTED; }
+    if (m != CTR_MODE_CONST && m != CTR_MODE_VAR && m != CTR_MODE_CLUSTER) { msg = "unknown param mode"; return CTR_ERR_INVALID; }
+  }
+  if (p->modes[0] == CTR_MODE_VAR) { msg = "background cannot vary per feature (fitfunc.py:389-392)"; return CTR_ERR_INVALID; }
+  for (int a = 0; a < p->ndim; ++a)
+    if (p->radius[a] < 1) { msg = "radius must be >= 1"; return CTR_ERR_INVALID; }
+  if (p->max_iter < 1) { msg = "max_iter must be >= 1"; return CTR_ERR_INVALID; }
+  if (p->constraint_kind < CTR_CONS_NONE || p->constraint_kind > CTR_CONS_TETRAMER) { msg = "unknown constraint kind"; return CTR_ERR_INVALID; }
+  if (p->constraint_kind != CTR_CONS_NONE)
+    for (int a = 0; a < p->ndim; ++a)
+      if (!(p->constraint_dist[a] > 0.)) { msg = "constraint distance must be positive"; return CTR_ERR_INVALID; }
+  if (!(p->residual_factor > 0.)) { msg = "residual_factor must be positive"; return CTR_ERR_INVALID; }
+  return CTR_OK;
+}
+
+int n_vars(const ctr_problem* p, int n) {
+  int nv = 0;
+  for (int k = 0; k < p->n_params; ++k) {
+    if (p->modes[k] == CTR_MODE_VAR) nv += n;
+    else if (p->modes[k] != CTR_MODE_CONST) nv += 1;
+  }
+  return nv;
+}
+
+size_t host_dtype_size(int dtype) {
+  switch (dtype) {
+    case CTR_DTYPE_U8: return 1;
+    case CTR_DTYPE_U16: case CTR_DTYPE_I16: return 2;
+    case CTR_DTYPE_I32: case CTR_DTYPE_F32: return 4;
+    case CTR_DTYPE_F64: return 8;
+    default: return 0;
+  }
+}
+
+int ensure_fmax(ctr_handle* h, int64_t n_frames) {
+  if (n_frames <= h->fmax_cap) return CTR_OK;
+  if (h->d_enc) { (void)hipFree(h->d_enc); h->d_enc = nullptr; }
+  if (h->d_fmax) { (void)hipFree(h->d_fmax); h->d_fmax = nullptr; }
+  h->fmax_cap = 0;
+  HIP_TRY(h, hipMalloc((void**)&h->d_enc, sizeof(unsigned long long) * (size_t)n_frames));
+  HIP_TRY(h, hipMalloc((void**)&h->d_fmax, sizeof(double) * (size_t)n_frames));
+  h->fmax_cap = n_frames;
+  return CTR_OK;
+}
+
+int launch_frame_max(ctr_handle* h, const void* frames, int dtype, int64_t n_frames,
+                     int64_t frame_elems, double* out, hipStream_t s) {
+  const size_t isz = host_dtype_size(dtype);
+  if (!isz) return fail(h, CTR_ERR_INVALID, "unknown frame dtype");
+  if (n_frames <= 0) return CTR_OK;
+  int rc = ensure_fmax(h, n_frames);
+  if (rc) return rc;
+  const size_t chunk_elems = FM_CHUNK_BYTES / isz;
+  const int chunks = (int)(((size_t)frame_elems + chunk_elems - 1) / chunk_elems);
+  HIP_TRY(h, hipMemsetAsync(h->d_enc, 0, sizeof(unsigned long long) * (size_t)n_frames, s));
+  const long long grid = (long long)n_frames * chunks;
+  if (grid > 0x7fffffffLL) return fail(h, CTR_ERR_INVALID, "frame block too large for one launch");
+  hipLaunchKernelGGL(frame_max_kernel, dim3((unsigned)grid), dim3(FM_THREADS), 0, s, frames, dtype,
+                     (size_t)frame_elems, chunks, chunk_elems, h->d_enc);
+  hipLaunchKernelGGL(frame_max_decode_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, s,
+                     h->d_enc, out, n_frames);
+  HIP_TRY(h, hipGetLastError());
+  return CTR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctr_abi_version(void) { return CTR_ABI_VERSION; }
+
+const char* ctr_last_error(const ctr_handle* h) {
+  if (h) return h->err.c_str();
+  return g_create_error.c_str();
+}
+
+int ctr_validate_problem(const ctr_problem* p, char* msg, int msg_len) {
+  std::string m;
+  const int rc = validate(p, m);
+  if (msg && msg_len > 0) {
+    std::snprintf(msg, (size_t)msg_len, "%s", m.c_str());
+  }
+  return rc;
+}
+
+int ctr_cluster_n_vars(const ctr_problem* p, int n_features) { return p ? n_vars(p, n_features) : -1; }
+
+int ctr_create(ctr_handle** out, int device) {
+  if (!out) return fail(nullptr, CTR_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(nullptr, CTR_ERR_DEVICE, std::string("no HIP device visible (") + hipGetErrorString(e) + "); there is no CPU fallback");
+  if (device < 0 || device >= count) return fail(nullptr, CTR_ERR_INVALID, "device index out of range");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, CTR_ERR_DEVICE, "hipGetDeviceProperties failed");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, CTR_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this engine is built for gfx950 (MI355X) only");
+  ctr_handle* h = new ctr_handle();
+  h->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return fail(nullptr, CTR_ERR_DEVICE, "cannot create a stream on the device");
+  }
+  for (auto& ev : h->ev)
+    if (hipEventCreate(&ev) != hipSuccess) { delete h; return fail(nullptr, CTR_ERR_DEVICE, "hipEventCreate failed"); }
+  fill_table<2, true>(h->table[0][1], h->smem_bytes[0][1]);
+  fill_table<2, false>(h->table[0][0], h->smem_bytes[0][0]);
+  fill_table<3, true>(h->table[1][1], h->smem_bytes[1][1]);
+  fill_table<3, false>(h->table[1][0], h->smem_bytes[1][0]);
+  *out = h;
+  return CTR_OK;
+}
+
+void ctr_destroy(ctr_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->d_buf) (void)hipFree(h->d_buf);
+  if (h->d_enc) (void)hipFree(h->d_enc);
+  if (h->d_fmax) (void)hipFree(h->d_fmax);
+  for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
+                    const int32_t* feat_offset_host, ctr_plan** out) {
+  if (!h || !out) return CTR_ERR_INVALID;
+  *out = nullptr;
+  std::string msg;
+  int rc = validate(p, msg);
+  if (rc) return fail(h, rc, msg);
+  if (n_clusters < 0 || (n_clusters > 0 && !feat_offset_host)) return fail(h, CTR_ERR_INVALID, "bad cluster table");
+  if (n_clusters > 0x7ffffff0LL) return fail(h, CTR_ERR_INVALID, "too many clusters for one batch");
+  std::vector<int32_t> bin_of((size_t)n_clusters);
+  ctr_plan* plan = new ctr_plan();
+  plan->prob = *p;
+  plan->n_clusters = n_clusters;
+  plan->device = h->device;
+  for (int64_t c = 0; c < n_clusters; ++c) {
+    const int64_t n = (int64_t)feat_offset_host[c + 1] - feat_offset_host[c];
+    if (n < 0) { delete plan; return fail(h, CTR_ERR_INVALID, "feat_offset must be non-decreasing"); }
+    int bin;
+    if (n > MAXF) bin = MAXNT;
+    else {
+      const int nv = n_vars(p, (int)n);
+      const int nt = (nv + 1 + 15) / 16;
+      bin = nt > MAXNT ? MAXNT : (nt < 1 ? 0 : nt - 1);
+      if (bin < MAXNT && n > (16 * (bin + 1) < MAXF ? 16 * (bin + 1) : MAXF)) bin = MAXNT;
+    }
+    bin_of[(size_t)c] = bin;
+    plan->bin_count[bin]++;
+  }
+  plan->bin_begin[0] = 0;
+  for (int b = 0; b <= MAXNT; ++b) plan->bin_begin[b + 1] = plan->bin_begin[b] + plan->bin_count[b];
+  std::vector<int32_t> order((size_t)n_clusters);
+  int64_t cursor[MAXNT + 1];
+  for (int b = 0; b <= MAXNT; ++b) cursor[b] = plan->bin_begin[b];
+  for (int64_t c = 0; c < n_clusters; ++c) order[(size_t)cursor[bin_of[(size_t)c]]++] = (int32_t)c;
+  if (n_clusters > 0) {
+    if (hipSetDevice(h->device) != hipSuccess ||
+        hipMalloc((void**)&plan->d_order, sizeof(int32_t) * (size_t)n_clusters) != hipSuccess) {
+      delete plan;
+      return fail(h, CTR_ERR_NOMEM, "cannot allocate the plan on the device");
+    }
+    if (hipMemcpy(plan->d_order, order.data(), sizeof(int32_t) * (size_t)n_clusters, hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(plan->d_order);
+      delete plan;
+      return fail(h, CTR_ERR_DEVICE, "cannot upload the plan");
+    }
+  }
+  *out = plan;
+  return CTR_OK;
+}
+
+void ctr_plan_destroy(ctr_plan* plan) {
+  if (!plan) return;
+  if (plan->d_order) { (void)hipSetDevice(plan->device); (void)hipFree(plan->d_order); }
+  delete plan;
+}
+
+int ctr_frame_max_device(ctr_handle* h, const void* frames, int32_t frame_dtype, int64_t n_frames,
+                         int64_t frame_elems, double* out_max, void* hip_stream) {
+  if (!h) return CTR_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  return launch_frame_max(h, frames, frame_dtype, n_frames, frame_elems, out_max, s);
+}
+
+int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch* b, void* hip_stream) {
+  if (!h || !plan || !b) return CTR_ERR_INVALID;
+  if (b->n_clusters != plan->n_clusters) return fail(h, CTR_ERR_INVALID, "batch does not match the plan");
+  const ctr_problem& p = plan->prob;
+  if (!host_dtype_size(b->frame_dtype)) return fail(h, CTR_ERR_INVALID, "unknown frame dtype");
+  for (int a = 0; a < p.ndim; ++a)
+    if (b->shape[a] < 1) return fail(h, CTR_ERR_INVALID, "frame shape must be positive");
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  int64_t frame_elems = 1;
+  for (int a = 0; a < p.ndim; ++a) frame_elems *= b->shape[a];
+  h->ev_valid = false;
+  HIP_TRY(h, hipEventRecord(h->ev[0], s));
+  int rc = ensure_fmax(h, b->n_frames > 0 ? b->n_frames : 1);
+  if (rc) return rc;
+  rc = launch_frame_max(h, b->frames, b->frame_dtype, b->n_frames, frame_elems, h->d_fmax, s);
+  if (rc) return rc;
+  HIP_TRY(h, hipEventRecord(h->ev[1], s));
+
+  KArgs k;
+  std::memset(&k, 0, sizeof k);
+  k.prob = p;
+  k.frames = b->frames;
+  k.frame_dtype = b->frame_dtype;
+  for (int a = 0; a < 3; ++a) k.shape[a] = a < p.ndim ? b->shape[a] : 1;
+  k.frame_elems = frame_elems;
+  k.frame_index = b->frame_index;
+  k.feat_offset = b->feat_offset;
+  k.params = b->params;
+  k.low = b->low;
+  k.high = b->high;
+  k.params_out = b->params_out;
+  k.cost = b->cost;
+  k.status = b->status;
+  k.n_rounds = b->n_rounds;
+  k.n_iter = b->n_iter;
+  k.fmax = h->d_fmax;
+  const int di = p.ndim == 3 ? 1 : 0, ii = p.isotropic ? 1 : 0;
+  for (int bin = 0; bin < MAXNT; ++bin) {
+    const int64_t cnt = plan->bin_count[bin];
+    if (cnt == 0) continue;
+    kernel_fn fn = h->table[di][ii][bin];
+    const size_t bytes = h->smem_bytes[di][ii][bin];
+    if (!h->attr_set[di][ii][bin]) {
+      HIP_TRY(h, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      h->attr_set[di][ii][bin] = true;
+    }
+    k.order = plan->d_order + plan->bin_begin[bin];
+    k.n_bin = (int32_t)cnt;
+    hipLaunchKernelGGL(fn, dim3((unsigned)cnt), dim3(WAVE), bytes, s, k);
+  }
+  if (plan->bin_count[MAXNT] > 0) {
+    const int64_t cnt = plan->bin_count[MAXNT];
+    k.order = plan->d_order + plan->bin_begin[MAXNT];
+    k.n_bin = (int32_t)cnt;
+    hipLaunchKernelGGL(mark_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, k,
+                       (int)CTR_STATUS_TOO_LARGE);
+  }
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipEventRecord(h->ev[2], s));
+  h->ev_valid = true;
+  return CTR_OK;
+}
+
+int ctr_synchronize(ctr_handle* h, void* hip_stream) {
+  if (!h) return CTR_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : h->stream));
+  return CTR_OK;
+}
+
+int ctr_last_kernel_ms(ctr_handle* h, double* frame_max_ms, double* refine_ms) {
+  if (!h) return CTR_ERR_INVALID;
+  if (!h->ev_valid) return fail(h, CTR_ERR_INVALID, "no ctr_refine_batch_device call to time");
+  HIP_TRY(h, hipEventSynchronize(h->ev[2]));
+  float a = 0.f, c = 0.f;
+  HIP_TRY(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+  HIP_TRY(h, hipEventElapsedTime(&c, h->ev[1], h->ev[2]));
+  if (frame_max_ms) *frame_max_ms = a;
+  if (refine_ms) *refine_ms = c;
+  return CTR_OK;
+}
+
+int ctr_refine_batch(ctr_handle* h, const ctr_problem* p, const ctr_batch* b) {
+  if (!h || !p || !b) return CTR_ERR_INVALID;
+  std::string msg;
+  int rc = validate(p, msg);
+  if (rc) return fail(h, rc, msg);
+  const size_t isz = host_dtype_size(b->frame_dtype);
+  if (!isz) return fail(h, CTR_ERR_INVALID, "unknown frame dtype");
+  if (b->n_clusters < 0 || b->n_features < 0 || b->n_frames < 0) return fail(h, CTR_ERR_INVALID, "negative counts");
+  if (b->n_clusters == 0) return CTR_OK;
+  if (!b->frames || !b->frame_index || !b->feat_offset || !b->params || !b->low || !b->high ||
+      !b->params_out || !b->cost || !b->status || !b->n_rounds || !b->n_iter)
+    return fail(h, CTR_ERR_INVALID, "null buffer in batch");
+  int64_t frame_elems = 1;
+  for (int a = 0; a < p->ndim; ++a) {
+    if (b->shape[a] < 1) return fail(h, CTR_ERR_INVALID, "frame shape must be positive");
+    frame_elems *= b->shape[a];
+  }
+  const int64_t C = b->n_clusters, N = b->n_features;
+  if (b->feat_offset[0] != 0 || b->feat_offset[C] != N) return fail(h, CTR_ERR_INVALID, "feat_offset must run from 0 to n_features");
+  for (int64_t c = 0; c < C; ++c) {
+    if (b->feat_offset[c + 1] < b->feat_offset[c]) return fail(h, CTR_ERR_INVALID, "feat_offset must be non-decreasing");
+    if (b->frame_index[c] < 0 || b->frame_index[c] >= b->n_frames) return fail(h, CTR_ERR_INVALID, "frame_index out of range");
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+
+  const size_t np = (size_t)p->n_params;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t sz_frames = al((size_t)b->n_frames * (size_t)frame_elems * isz);
+  const size_t sz_fi = al(sizeof(int32_t) * (size_t)C), sz_fo = al(sizeof(int32_t) * (size_t)(C + 1));
+  const size_t sz_par = al(sizeof(double) * (size_t)N * np);
+  const size_t sz_c = al(sizeof(double) * (size_t)C), sz_ci = al(sizeof(int32_t) * (size_t)C);
+  const size_t total = sz_frames + sz_fi + sz_fo + 4 * sz_par + sz_c + 3 * sz_ci;
+  if (total > h->d_buf_bytes) {
+    if (h->d_buf) { (void)hipFree(h->d_buf); h->d_buf = nullptr; h->d_buf_bytes = 0; }
+    if (hipMalloc(&h->d_buf, total) != hipSuccess) return fail(h, CTR_ERR_NOMEM, "cannot allocate device memory for the batch");
+    h->d_buf_bytes = total;
+  }
+  char* q = (char*)h->d_buf;
+  ctr_batch d = *b;
+  auto take = [&](size_t n) { char* r = q; q += n; return r; };
+  char* d_frames = take(sz_frames);
+  int32_t* d_fi = (int32_t*)take(sz_fi);
+  int32_t* d_fo = (int32_t*)take(sz_fo);
+  double* d_par = (double*)take(sz_par);
+  double* d_low = (double*)take(sz_par);
+  double* d_high = (double*)take(sz_par);
+  double* d_out = (double*)take(sz_par);
+  double* d_cost = (double*)take(sz_c);
+  int32_t* d_status = (int32_t*)take(sz_ci);
+  int32_t* d_rounds = (int32_t*)take(sz_ci);
+  int32_t* d_iter = (int32_t*)take(sz_ci);
+  hipStream_t s = h->stream;
+  HIP_TRY(h, hipMemcpyAsync(d_frames, b->frames, (size_t)b->n_frames * (size_t)frame_elems * isz, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(d_fi, b->frame_index, sizeof(int32_t) * (size_t)C, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(d_fo, b->feat_offset, sizeof(int32_t) * (size_t)(C + 1), hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(d_par, b->params, sizeof(double) * (size_t)N * np, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(d_low, b->low, sizeof(double) * (size_t)N * np, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(d_high, b->high, sizeof(double) * (size_t)N * np, hipMemcpyHostToDevice, s));
+  d.frames = d_frames; d.frame_index = d_fi; d.feat_offset = d_fo;
+  d.params = d_par; d.low = d_low; d.high = d_high; d.params_out = d_out;
+  d.cost = d_cost; d.status = d_status; d.n_rounds = d_rounds; d.n_iter = d_iter;
+  ctr_plan* plan = nullptr;
+  rc = ctr_plan_create(h, p, C, b->feat_offset, &plan);
+  if (rc) return rc;
+  rc = ctr_refine_batch_device(h, plan, &d, s);
+  if (rc == CTR_OK) {
+    hipError_t e = hipMemcpyAsync(b->params_out, d_out, sizeof(double) * (size_t)N * np, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(b->cost, d_cost, sizeof(double) * (size_t)C, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(b->status, d_status, sizeof(int32_t) * (size_t)C, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(b->n_rounds, d_rounds, sizeof(int32_t) * (size_t)C, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(b->n_iter, d_iter, sizeof(int32_t) * (size_t)C, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) rc = fail(h, CTR_ERR_DEVICE, std::string("copy back / kernel execution: ") + hipGetErrorString(e));
+  } else {
+    (void)hipStreamSynchronize(s);
+  }
+  ctr_plan_destroy(plan);
+  return rc;
+}
+
+}  // extern "C"
