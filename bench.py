@@ -1,0 +1,196 @@
+"""Benchmark of the refine hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE.json configs[1] -- 256 synthetic 512x512
+uint8 frames PER GPU, ~200 Gaussians per frame (size 3 = radius of gyration,
+diameter 13, signal 100, Poisson noise 10, seed = global frame index), isotropic
+Gaussian model, default param modes.  A "step" is one pass of the hot path over
+that batch with every input already resident in HBM: per-frame maximum kernel +
+refine kernels (windows, masks, LM fits, re-window rounds); with N > 1 each rank
+owns a contiguous block of frames (no data-path collective) and the step ends
+with the RCCL gather of the result rows to rank 0.  value = cluster-fits of all
+ranks / max-over-ranks wall time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--frames', type=int, default=256, help='frames per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(problem, host_batch):
+    """The C oracle (oracle/ctr_oracle.c: same algorithm as the engine, scalar
+    C + OpenMP over clusters) timed on the host cores of this box."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import ctr_oracle
+    ctr_oracle.load()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    out = {}
+    for key, threads in (('all', cores), ('one', 1)):
+        t0 = time.perf_counter()
+        ctr_oracle.run_batch(problem, host_batch, threads)
+        dt = time.perf_counter() - t0
+        out[key] = (host_batch.n_clusters / dt, threads, dt)
+    return out
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import clustertracking_amd as cta
+    from clustertracking_amd import workloads
+    from clustertracking_amd.device import DeviceBatch
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    # ---- this rank's shard: frames [rank*F, (rank+1)*F) of the video --------------
+    frames, f0, truth, opts = workloads.cfg2(args.frames, first_seed=rank * args.frames)
+    reader = cta.ArrayReader(frames)
+    t0 = time.perf_counter()
+    prep = cta.prepare_batch(f0, reader, opts['diameter'])
+    t_host_prep = time.perf_counter() - t0
+    db = DeviceBatch(prep.problem, prep.batch, device=local_rank)
+    n_fits = prep.batch.n_clusters
+    n_feat = prep.batch.n_features
+    stream = torch.cuda.current_stream().cuda_stream
+
+    gather_buf = None
+    if world > 1:
+        counts = [torch.zeros(1, dtype=torch.int64, device='cuda') for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([n_feat], dtype=torch.int64, device='cuda'))
+        counts = [int(c.item()) for c in counts]
+        width = prep.batch.params.shape[1] + 1
+        pad = max(counts)
+        if rank == 0:
+            gather_buf = [torch.empty((pad, width), dtype=torch.float64, device='cuda')
+                          for _ in range(world)]
+        send = torch.zeros((pad, width), dtype=torch.float64, device='cuda')
+
+    def step():
+        db.run(stream)
+        if world > 1:
+            send[:n_feat] = db.results_tensor()
+            dist.gather(send, gather_buf, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    fm_ms, rf_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    # kernel durations: HIP events recorded on the launch stream inside the library
+    for _ in range(5):
+        db.run(stream)
+        a, b = db.engine.last_kernel_ms()
+        fm_ms.append(a)
+        rf_ms.append(b)
+    fence()
+
+    t_all = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    fits_all = torch.tensor([float(n_fits)], dtype=torch.float64, device='cuda')
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        dist.all_reduce(fits_all, op=dist.ReduceOp.SUM)
+    elapsed = float(t_all.item())
+    total_fits = float(fits_all.item())
+
+    # ---- correctness of what was timed (rank 0): oracle on the same batch ---------
+    hb = db.download()
+    n_fail = int((hb.status != 0).sum())
+    gpu_out, gpu_status = hb.params_out.copy(), hb.status.copy()
+    mean_iters = float(hb.n_iter.mean())
+    result = None
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = total_fits * args.steps / elapsed
+        alg_bytes = db.algorithmic_bytes()
+        rf = float(np.median(rf_ms)) * 1e-3
+        fm = float(np.median(fm_ms)) * 1e-3
+        peak = 8000.0
+        result = {
+            "metric": "cluster-fits/sec", "value": value, "unit": "cluster-fits/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cfg2: %d frames/GPU of 512x512 uint8, 200 Gaussians/frame, "
+                                   "size 3 (radius of gyration), diameter 13, Poisson noise 10, "
+                                   "isotropic Gaussian model, default param modes" % args.frames,
+                       "frames_per_gpu": args.frames, "cluster_fits_per_gpu": n_fits,
+                       "features_per_gpu": n_feat, "parallelism": "frames sharded, %d rank(s)" % world},
+            "features_per_s": value * n_feat / max(n_fits, 1),
+            "failed_clusters": n_fail,
+            "mean_solver_iterations": mean_iters,
+            "roofline": {"bound": "hbm", "kernel": "refine_kernel<2,iso,NT=1> (all bins)",
+                         "achieved": alg_bytes / rf / 1e9, "peak": peak, "unit": "GB/s",
+                         "frac": alg_bytes / rf / 1e9 / peak, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": rf * 1e3},
+            "roofline_frame_max": {"bound": "hbm", "kernel": "frame_max_kernel",
+                                   "achieved": hb.frames.nbytes / fm / 1e9, "peak": peak,
+                                   "unit": "GB/s", "frac": hb.frames.nbytes / fm / 1e9 / peak,
+                                   "kernel_ms": fm * 1e3},
+            "host_prepare_s": t_host_prep,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base = cpu_baseline(prep.problem, prep.batch)
+            # the oracle overwrote the host outputs with its own: compare with the GPU's
+            both = (hb.status == 0) & (gpu_status == 0)
+            result["status_equal_oracle"] = bool((hb.status == gpu_status).all())
+            pos = slice(2, 4)
+            ok_rows = np.repeat(both, np.diff(hb.feat_offset))
+            dpos = (gpu_out[:, pos] - hb.params_out[:, pos])[ok_rows]
+            result["parity_vs_oracle_px"] = {"rmse": float(np.sqrt(np.mean(dpos ** 2))),
+                                             "max": float(np.abs(dpos).max())}
+            result["cpu_baseline"] = {
+                "value": base['all'][0], "unit": "cluster-fits/s", "cores": base['all'][1],
+                "kind": "port", "sample": "the full workload of one GPU (%d cluster-fits), "
+                "C oracle, OpenMP over clusters" % n_fits,
+                "one_thread_value": base['one'][0],
+                "reference_python_fits_per_s": 109.0,
+                "reference_python_note": "reference refine_leastsq (SciPy SLSQP), 1 thread, "
+                                         "measured in the survey container (BASELINE.md section 2); "
+                                         "it cannot run on the GPU box"}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

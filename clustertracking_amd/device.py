@@ -1,0 +1,77 @@
+"""Device-resident batches: inputs live in HBM (torch tensors are used only as
+device memory + stream plumbing), the engine runs asynchronously on a HIP
+stream through ``ctr_refine_batch_device`` (include/ctrefine.h)."""
+import numpy as np
+
+from . import _abi, _lib
+
+
+class DeviceBatch(object):
+    """A HostBatch uploaded once; ``run()`` queues one pass of the hot path."""
+
+    def __init__(self, problem, host_batch, device=0, engine=None):
+        import torch
+        self.torch = torch
+        self.device = torch.device('cuda', device)
+        self.engine = engine or _lib.default_engine(device)
+        self.problem = problem
+        self.host = host_batch
+        hb = host_batch
+        frames = hb.frames
+        if frames.dtype == np.uint16:   # torch has no uint16 arithmetic; bytes are what travels
+            frames_t = torch.from_numpy(frames.view(np.int16))
+        else:
+            frames_t = torch.from_numpy(frames)
+        with torch.cuda.device(self.device):
+            self.t = dict(
+                frames=frames_t.to(self.device),
+                frame_index=torch.from_numpy(hb.frame_index).to(self.device),
+                feat_offset=torch.from_numpy(hb.feat_offset).to(self.device),
+                params=torch.from_numpy(hb.params).to(self.device),
+                low=torch.from_numpy(hb.low).to(self.device),
+                high=torch.from_numpy(hb.high).to(self.device),
+                params_out=torch.empty(hb.params.shape, dtype=torch.float64, device=self.device),
+                cost=torch.empty(hb.n_clusters, dtype=torch.float64, device=self.device),
+                status=torch.empty(hb.n_clusters, dtype=torch.int32, device=self.device),
+                n_rounds=torch.empty(hb.n_clusters, dtype=torch.int32, device=self.device),
+                n_iter=torch.empty(hb.n_clusters, dtype=torch.int32, device=self.device),
+            )
+            torch.cuda.synchronize(self.device)
+        b = hb.as_struct()
+        for name, tensor in self.t.items():
+            setattr(b, name, tensor.data_ptr())
+        self.struct = b
+        self.plan = self.engine.plan(problem, hb.feat_offset)
+
+    def run(self, stream=None):
+        """Queue frame-max + refine kernels on ``stream`` (default: torch's
+        current stream on this device)."""
+        if stream is None:
+            stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        self.engine.refine_batch_device(self.plan, self.struct, stream)
+
+    def download(self):
+        """Copy the outputs back into the HostBatch arrays (synchronises)."""
+        self.torch.cuda.synchronize(self.device)
+        hb = self.host
+        hb.params_out[...] = self.t['params_out'].cpu().numpy()
+        hb.cost[...] = self.t['cost'].cpu().numpy()
+        hb.status[...] = self.t['status'].cpu().numpy()
+        hb.n_rounds[...] = self.t['n_rounds'].cpu().numpy()
+        hb.n_iter[...] = self.t['n_iter'].cpu().numpy()
+        return hb
+
+    def results_tensor(self):
+        """[N, n_params + 1] f64 on the device: refined parameters and the
+        cost of the feature's cluster -- the rows that are gathered across ranks."""
+        torch = self.torch
+        n_per = torch.from_numpy(np.diff(self.host.feat_offset).astype(np.int64)).to(self.device)
+        cost_rows = torch.repeat_interleave(self.t['cost'], n_per)
+        return torch.cat([self.t['params_out'], cost_rows[:, None]], dim=1)
+
+    def algorithmic_bytes(self):
+        """one read of every frame + per feature 2*n_params*8
+        (p0 in, params out) + per cluster 16 (cost, status, counters)."""
+        hb = self.host
+        return int(hb.frames.nbytes + hb.n_features * 2 * hb.params.shape[1] * 8 +
+                   hb.n_clusters * 16)
