@@ -646,10 +646,11 @@ int ctro_refine_batch(const ctr_problem* p, const ctr_batch* b, int n_threads) {
 
 /* Known answer: objective F and its gradient in the reference's normalisation
  * (fitfunc.py:436-487) at the packed start vector of cluster `cl`, first-round
- * window.  vect/grad: [nv]; bounds: [nv][2] (compute_bounds layout). */
+ * window.  vect/grad: [nv]; bounds: [nv][2] (compute_bounds layout).  With
+ * v_in != NULL the objective is evaluated at v_in instead (masks unchanged). */
 int ctro_objective(const ctr_problem* p, const ctr_batch* b, int64_t cl, double* F,
                    double* vect, double* grad, double* bounds, int32_t* origin,
-                   int32_t* wshape, int64_t* P_out) {
+                   int32_t* wshape, int64_t* P_out, const double* v_in) {
   const int32_t f0 = b->feat_offset[cl], f1 = b->feat_offset[cl + 1];
   const int n = f1 - f0, np = p->n_params, nd = p->ndim;
   const double* params = b->params + (size_t)f0 * np;
@@ -672,6 +673,7 @@ int ctro_objective(const ctr_problem* p, const ctr_batch* b, int64_t cl, double*
   if (!window(nd, b->shape, p->radius, coords, n, c.origin, c.wshape)) { free(fmax); free(coords); return -2; }
   c.mcoords = coords;
   pack_start(&c, params, b->low + (size_t)f0 * np, b->high + (size_t)f0 * np, vect, lo, hi);
+  if (v_in) memcpy(vect, v_in, sizeof(double) * c.L.nv); /* evaluate elsewhere, masks stay at p0 */
   A = malloc(sizeof(double) * c.L.nv * c.L.nv);
   eval_cluster(&c, vect, &S, grad, A, &P);
   {

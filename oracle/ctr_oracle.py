@@ -35,7 +35,7 @@ def load():
         lib.ctro_mask_counts.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
         lib.ctro_mask_counts.restype = C.c_long
         lib.ctro_objective.argtypes = [P(_abi.Problem), P(_abi.Batch), C.c_int64] + \
-            [C.c_void_p] * 7
+            [C.c_void_p] * 8
         lib.ctro_objective.restype = C.c_int
         _lib = lib
     return _lib
@@ -78,8 +78,9 @@ def mask_counts(shape, radius, coords):
     return P, per
 
 
-def objective(problem, batch, cluster):
-    """(F, vect, grad, bounds[nv,2], origin, wshape, P) at the packed start vector."""
+def objective(problem, batch, cluster, v_in=None):
+    """(F, vect, grad, bounds[nv,2], origin, wshape, P) at the packed start vector
+    (or at ``v_in`` with the masks kept at the start coordinates)."""
     from clustertracking_amd import _abi
     lib = load()
     b = batch.as_struct()
@@ -93,7 +94,9 @@ def objective(problem, batch, cluster):
     nv = lib.ctro_objective(C.byref(problem), C.byref(b), int(cluster),
                             C.addressof(F), vect.ctypes.data, grad.ctypes.data,
                             bounds.ctypes.data, origin.ctypes.data, wshape.ctypes.data,
-                            C.addressof(P))
+                            C.addressof(P),
+                            None if v_in is None else
+                            np.ascontiguousarray(v_in, dtype=np.float64).ctypes.data)
     if nv < 0:
         raise ValueError("ctro_objective failed (%d)" % nv)
     nd = problem.ndim

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    """The C oracle (oracle/ctr_oracle.c), built on demand."""
+    import ctr_oracle
+    ctr_oracle.load()
+    return ctr_oracle
+
+
+@pytest.fixture(scope='session')
+def engine():
+    """The HIP engine on cuda:0; fails loudly when library or GPU is missing."""
+    from clustertracking_amd import _lib
+    return _lib.default_engine(0)

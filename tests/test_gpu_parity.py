@@ -1,0 +1,252 @@
+"""Parity of the HIP engine (through the C-ABI of include/ctrefine.h) with the
+CPU oracle and with the reference's golden outputs.  Needs a real MI355X.
+
+Tolerances (float64, pixels): engine vs C oracle 1e-7 px max (same algorithm,
+different summation order and exp implementation), cost 1e-10; engine vs the
+reference as in tests/test_golden_oracle.py."""
+import numpy as np
+import pandas as pd
+import pytest
+from numpy.testing import assert_allclose, assert_equal
+
+import _cases
+import clustertracking_amd as cta
+from clustertracking_amd import _abi, workloads
+
+pytestmark = pytest.mark.gpu
+
+CASES = _cases.case_names()
+BETTER_MINIMUM = {'video_2frames': 1}
+
+
+def assert_batches_close(b_gpu, b_ref, pos_slice, atol=1e-7):
+    assert_equal(b_gpu.status, b_ref.status)
+    ok = b_gpu.status == 0
+    assert_allclose(b_gpu.cost[ok], b_ref.cost[ok], rtol=0, atol=1e-10)
+    assert np.isnan(b_gpu.cost[~ok]).all()
+    rows = np.repeat(ok, np.diff(b_gpu.feat_offset))
+    d = np.abs(b_gpu.params_out[:, pos_slice] - b_ref.params_out[:, pos_slice])[rows]
+    assert d.max() < atol, d.max()
+    assert_allclose(b_gpu.params_out[rows], b_ref.params_out[rows], rtol=1e-7, atol=1e-7)
+    assert_equal(b_gpu.params_out[~rows], b_gpu.params[~rows])   # failures keep their input
+
+
+def clone_batch(b):
+    return _abi.HostBatch(b.frames, b.frame_index, b.feat_offset, b.params, b.low, b.high)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_case_engine_vs_oracle_and_reference(engine, oracle, name):
+    case = _cases.Case(name)
+    prep = case.prepare()
+    ref_batch = clone_batch(prep.batch)
+    engine.refine_batch(prep.problem, prep.batch)
+    oracle.run_batch(prep.problem, ref_batch)
+    nd = len(case.pos_columns)
+    assert_batches_close(prep.batch, ref_batch, slice(2, 2 + nd))
+    assert_equal(prep.batch.n_rounds, ref_batch.n_rounds)
+    res = cta.write_back(prep)
+    if case.ref_aborts:
+        return
+    A, B = case.ref('A'), case.ref('B')
+    pc = case.pos_columns
+    assert_equal(np.isnan(res['cost'].values), np.isnan(B['cost'].values))
+    ok = ~np.isnan(res['cost'].values)
+    better = ok & (res['cost'].values < B['cost'].values - 1e-7)
+    assert len(set(res['cluster'].values[better])) <= BETTER_MINIMUM.get(name, 0)
+    rows = ok & ~better
+    assert np.abs(res[pc].values - B[pc].values)[rows].max() < 1e-6
+    assert_allclose(res['cost'].values[rows], B['cost'].values[rows], atol=1e-9)
+    rmse_A = np.sqrt(np.mean((res[pc].values - A[pc].values)[rows] ** 2))
+    rmse_AB = np.sqrt(np.mean((A[pc].values - B[pc].values)[rows] ** 2))
+    assert rmse_A <= max(1.5 * rmse_AB, 1e-5)
+
+
+def test_drop_in_call_uses_the_engine(engine):
+    """refine_leastsq with no hook goes through libctrefine.so on cuda:0."""
+    case = _cases.Case('cfg1_triple')
+    res = case.run(None)
+    B = case.ref('B')
+    assert np.abs(res[['y', 'x']].values - B[['y', 'x']].values).max() < 1e-6
+
+
+@pytest.fixture(scope='module')
+def cfg2_full():
+    frames, f0, truth, opts = workloads.cfg2(256, 0)
+    prep = cta.prepare_batch(f0, cta.ArrayReader(frames), opts['diameter'])
+    return prep, truth
+
+
+def test_cfg2_full_size_vs_oracle_and_truth(engine, oracle, cfg2_full):
+    """BASELINE cfg 2 at full size: 256 frames of 512x512, ~41k cluster fits."""
+    prep, truth = cfg2_full
+    b = clone_batch(prep.batch)
+    ref = clone_batch(prep.batch)
+    engine.refine_batch(prep.problem, b)
+    oracle.run_batch(prep.problem, ref, n_threads=16)
+    assert_batches_close(b, ref, slice(2, 4), atol=1e-6)
+    assert (b.status == 0).mean() > 0.999
+    # accuracy bar of the reference's own suite at S/N 10 (tests/test_refine.py:40)
+    ok_rows = np.repeat(b.status == 0, np.diff(b.feat_offset))
+    out = np.empty_like(b.params_out)
+    out[prep.order] = b.params_out
+    okr = np.empty(len(ok_rows), bool)
+    okr[prep.order] = ok_rows
+    rms = np.sqrt(np.mean((out[:, 2:4] - truth)[okr] ** 2))
+    assert rms < 0.05, rms
+
+
+def test_cfg2_cluster_order_invariance(engine, cfg2_full):
+    """Clusters are independent problems (refine.py:343): any order of the batch
+    gives bit-identical per-cluster results."""
+    prep, _ = cfg2_full
+    hb = prep.batch
+    sel = np.arange(0, hb.n_clusters, 7)
+    rng = np.random.RandomState(0)
+    perm = rng.permutation(sel)
+
+    def sub(order):
+        rows = np.concatenate([np.arange(hb.feat_offset[c], hb.feat_offset[c + 1]) for c in order])
+        off = np.concatenate([[0], np.cumsum(np.diff(hb.feat_offset)[order])])
+        return _abi.HostBatch(hb.frames, hb.frame_index[order], off, hb.params[rows],
+                              hb.low[rows], hb.high[rows])
+    b1, b2 = sub(sel), sub(perm)
+    engine.refine_batch(prep.problem, b1)
+    engine.refine_batch(prep.problem, b2)
+    inv = np.argsort(np.argsort(perm))   # position of sel[k] inside perm ... via values
+    pos_in_perm = {c: i for i, c in enumerate(perm)}
+    for k, c in enumerate(sel[:500]):
+        j = pos_in_perm[c]
+        assert b1.cost[k] == b2.cost[j] or (np.isnan(b1.cost[k]) and np.isnan(b2.cost[j]))
+        assert_equal(b1.params_out[b1.feat_offset[k]:b1.feat_offset[k + 1]],
+                     b2.params_out[b2.feat_offset[j]:b2.feat_offset[j + 1]])
+
+
+def test_translation_equivariance(engine):
+    """Embedding the frame at an integer offset shifts every fitted position by
+    exactly that offset (windows, masks and the model only see differences)."""
+    frames, f0, truth, opts = workloads.cfg2(2, 77)
+    dy, dx = 37, 64
+    big = np.zeros((2, 512 + 100, 512 + 100), np.uint8)
+    big[:, dy:dy + 512, dx:dx + 512] = frames
+    f1 = f0.copy()
+    f1['y'] += dy
+    f1['x'] += dx
+    r0 = cta.refine_leastsq(f0, cta.ArrayReader(frames), 13)
+    r1 = cta.refine_leastsq(f1, cta.ArrayReader(big), 13)
+    ok = ~np.isnan(r0['cost'].values)
+    assert_equal(ok, ~np.isnan(r1['cost'].values))
+    assert_allclose(r1['y'].values[ok] - dy, r0['y'].values[ok], rtol=0, atol=1e-8)
+    assert_allclose(r1['x'].values[ok] - dx, r0['x'].values[ok], rtol=0, atol=1e-8)
+    assert_allclose(r1['signal'].values[ok], r0['signal'].values[ok], rtol=1e-9)
+    assert_allclose(r1['cost'].values[ok], r0['cost'].values[ok], rtol=1e-9)
+
+
+def test_device_resident_path_equals_host_path(engine, cfg2_full):
+    import torch
+    from clustertracking_amd.device import DeviceBatch
+    prep, _ = cfg2_full
+    hb = prep.batch
+    sel = np.arange(0, 2000)
+    rows = np.arange(hb.feat_offset[0], hb.feat_offset[2000])
+    small = _abi.HostBatch(hb.frames[:16], hb.frame_index[sel], hb.feat_offset[:2001],
+                           hb.params[rows], hb.low[rows], hb.high[rows])
+    assert small.frame_index.max() < 16
+    a = clone_batch(small)
+    engine.refine_batch(prep.problem, a)
+    db = DeviceBatch(prep.problem, small, device=0, engine=engine)
+    db.run()
+    db.download()
+    assert_equal(small.status, a.status)
+    assert_equal(small.params_out, a.params_out)
+    fm, rf = engine.last_kernel_ms()
+    assert fm > 0 and rf > 0
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.int32, np.float32, np.float64])
+def test_frame_max_kernel_exact(engine, dtype):
+    import torch
+    rng = np.random.RandomState(5)
+    for shape in ((3, 512, 512), (5, 33, 47), (2, 9, 17, 31), (1, 1, 1)):
+        if np.issubdtype(dtype, np.integer):
+            info = np.iinfo(dtype)
+            arr = rng.randint(max(info.min, -1000), min(info.max, 30000) + 1, shape).astype(dtype)
+        else:
+            arr = (rng.standard_normal(shape) * 100).astype(dtype)
+        host = arr.view(np.int16) if dtype == np.uint16 else arr
+        t = torch.from_numpy(host).cuda()
+        out = torch.empty(shape[0], dtype=torch.float64, device='cuda')
+        engine.frame_max_device(t.data_ptr(), _abi.DTYPE_CODES[np.dtype(dtype)], shape[0],
+                                int(np.prod(shape[1:])), out.data_ptr())
+        engine.synchronize()
+        assert_equal(out.cpu().numpy(), arr.reshape(shape[0], -1).max(1).astype(np.float64))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16, np.int32, np.float32, np.float64])
+def test_pixel_types(engine, oracle, dtype):
+    im, truth, p0 = cta.artificial.random_frame((96, 96), 12, 3., 100, 10, 8, margin=13)
+    f0 = pd.DataFrame(p0, columns=['y', 'x'])
+    f0['signal'], f0['size'], f0['background'] = 90., 3., 5.
+    prep = cta.prepare_batch(f0, im.astype(dtype), 13)
+    assert prep.batch.frames.dtype == np.dtype(dtype)
+    ref = clone_batch(prep.batch)
+    engine.refine_batch(prep.problem, prep.batch)
+    oracle.run_batch(prep.problem, ref)
+    assert_batches_close(prep.batch, ref, slice(2, 4))
+
+
+def test_cfg3_3d_stacks_vs_oracle(engine, oracle):
+    frames, f0, truth, opts = workloads.cfg3(1, 0, n_features=120)
+    for mode in (None, dict(size='var')):
+        prep = cta.prepare_batch(f0.copy(), cta.ArrayReader(frames), opts['diameter'],
+                                 param_mode=mode)
+        ref = clone_batch(prep.batch)
+        engine.refine_batch(prep.problem, prep.batch)
+        oracle.run_batch(prep.problem, ref, n_threads=16)
+        assert_batches_close(prep.batch, ref, slice(2, 5), atol=1e-6)
+        assert (prep.batch.status == 0).mean() > 0.9
+
+
+def test_cfg5_dense_clusters_and_dimers_vs_oracle(engine, oracle):
+    frames, f0, truth, opts = workloads.cfg5(2, 0)
+    cons = cta.constraints.dimer(6., 2)
+    prep = cta.prepare_batch(f0, cta.ArrayReader(frames), opts['diameter'], constraints=cons)
+    sizes = np.diff(prep.batch.feat_offset)
+    assert sizes.max() >= 12 and (sizes == 2).any()
+    ref = clone_batch(prep.batch)
+    engine.refine_batch(prep.problem, prep.batch)
+    oracle.run_batch(prep.problem, ref, n_threads=16)
+    assert_batches_close(prep.batch, ref, slice(2, 4), atol=1e-6)
+    # constrained dimers sit at the prescribed distance (constraints.py:59-61)
+    b = prep.batch
+    for c in np.flatnonzero((sizes == 2) & (b.status == 0)):
+        p = b.params_out[b.feat_offset[c]:b.feat_offset[c + 1], 2:4]
+        assert abs(np.sqrt(((p[0] - p[1]) ** 2).sum()) - 6.) < 1e-8
+
+
+def test_too_large_cluster_is_data_not_error(engine):
+    """More features than the engine holds in one wave -> status 5, NaN cost."""
+    n = 70
+    im = np.zeros((64, 64), np.uint8)
+    p0 = np.column_stack([np.full(n, 32.), np.linspace(20, 44, n)])
+    f0 = pd.DataFrame(p0, columns=['y', 'x'])
+    f0['signal'], f0['size'] = 90., 3.
+    prep = cta.prepare_batch(f0, im + 1, 13)
+    assert prep.batch.n_clusters == 1
+    engine.refine_batch(prep.problem, prep.batch)
+    assert prep.batch.status[0] == _abi.STATUS_TOO_LARGE
+    assert np.isnan(prep.batch.cost[0])
+    assert_equal(prep.batch.params_out, prep.batch.params)
+
+
+def test_empty_batch_and_bad_descriptor(engine):
+    f0 = pd.DataFrame(dict(y=[], x=[], signal=[], size=[]))
+    res = cta.refine_leastsq(f0, np.zeros((32, 32), np.uint8), 13)
+    assert len(res) == 0 and 'cost' in res
+    prob = _abi.make_problem(2, True, [3, 1, 1, 1, 0], (6, 6))
+    b = _abi.HostBatch(np.zeros((1, 16, 16), np.uint8), [0], [0, 1], np.zeros((1, 5)),
+                       np.zeros((1, 5)), np.ones((1, 5)))
+    b.frame_index[0] = 3
+    with pytest.raises(ValueError):
+        engine.refine_batch(prob, b)
