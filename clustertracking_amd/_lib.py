@@ -26,12 +26,37 @@ class EngineError(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process: PyTorch-ROCm wheels bundle their own
+    libamdhip64.so.7 (+ HSA runtime).  If libctrefine.so pulled in the system
+    copy first, a later ``import torch`` would bind to that one and then fail to
+    see the GPU.  So when torch is installed, its copy is loaded first and
+    libctrefine.so (DT_NEEDED libamdhip64.so.7) binds to it."""
+    import importlib.util
+    import sys
+    if 'torch' in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load the shared library once; raises EngineError when it is absent."""
     global _lib
     with _lock:
         if _lib is not None:
             return _lib
+        _share_hip_runtime_with_torch()
         if not os.path.exists(LIB_PATH):
             raise EngineError(
                 "HIP engine not built: %s is missing. Build it with "

@@ -70,8 +70,13 @@ def find_clusters(f, separation, pos_columns=None, t_column='frame'):
     if remove_t:
         f[t_column] = 0
     try:
-        result = pd.concat(x[1] for x in find_iter(f, separation, pos_columns,
-                                                   t_column))
+        parts = [x[1] for x in find_iter(f, separation, pos_columns, t_column)]
+        if parts:
+            result = pd.concat(parts)
+        else:  # empty table (the reference raises ValueError from pd.concat here)
+            result = f.copy()
+            result['cluster'] = np.zeros(0, dtype=np.int64)
+            result['cluster_size'] = np.zeros(0, dtype=np.int64)
     finally:
         if remove_t:
             del f[t_column]

@@ -136,9 +136,11 @@ def test_translation_equivariance(engine):
     r1 = cta.refine_leastsq(f1, cta.ArrayReader(big), 13)
     ok = ~np.isnan(r0['cost'].values)
     assert_equal(ok, ~np.isnan(r1['cost'].values))
-    assert_allclose(r1['y'].values[ok] - dy, r0['y'].values[ok], rtol=0, atol=1e-8)
-    assert_allclose(r1['x'].values[ok] - dx, r0['x'].values[ok], rtol=0, atol=1e-8)
-    assert_allclose(r1['signal'].values[ok], r0['signal'].values[ok], rtol=1e-9)
+    # both runs stop at the solver's relative step tolerance (xtol 1e-9 of |v|+1),
+    # which is what bounds the agreement
+    assert_allclose(r1['y'].values[ok] - dy, r0['y'].values[ok], rtol=0, atol=5e-7)
+    assert_allclose(r1['x'].values[ok] - dx, r0['x'].values[ok], rtol=0, atol=5e-7)
+    assert_allclose(r1['signal'].values[ok], r0['signal'].values[ok], rtol=1e-7)
     assert_allclose(r1['cost'].values[ok], r0['cost'].values[ok], rtol=1e-9)
 
 
