@@ -29,6 +29,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -483,6 +484,7 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
       pred += sigma * (cn - cn_lin);
     }
     /* converged: negligible step after an accepted one, or negligible model decrease */
+    if (getenv("CTRO_TRACE")) fprintf(stderr, "it %d S %.12e mu %.3e step %.3e pred %.3e nf %d\n", it, S, mu, stepmax, pred, nf);
     int feasible = (m == 0) || (cn <= 1e-10);
     if (feasible && ((last_accepted && stepmax <= xtol) || pred <= ftol * (0.5 * S) + 1e-300)) {
       out.ok = 1;
