@@ -10,7 +10,7 @@ import threading
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libctrefine.so')
+LIB_PATH = os.environ.get('CTREFINE_LIB') or os.path.join(_HERE, 'csrc', 'libctrefine.so')
 
 # every symbol include/ctrefine.h declares
 EXPORTS = ('ctr_abi_version', 'ctr_create', 'ctr_destroy', 'ctr_last_error',

@@ -188,6 +188,15 @@ __device__ __forceinline__ double readlane_f64(double x, int srclane) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// 1/sqrt(x) to double precision: hardware estimate + two Newton steps (the
+// correctly rounded sqrt and division cost ~60 dependent instructions per pivot)
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  return r;
+}
+
 template <int NR>
 __device__ __forceinline__ bool column_solve(const double* Mp, int nv, double mu, bool is_free,
                                              int lane, double& x_own) {
@@ -208,26 +217,30 @@ __device__ __forceinline__ bool column_solve(const double* Mp, int nv, double mu
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
-    const double dj = readlane_f64(col[j], j);
-    if (!(dj > 0.) || !isfinite(dj)) ok = false;
-    const double dinv = 1. / sqrt(dj);
-    const double lkj = c > j ? col[j] * dinv : 0.;  // L[c][j] for the columns still open
-    const double yj = readlane_f64(y, j) * dinv;
-    if (c == j) { mydinv = dinv; yown = yj; }
+    if (j < nv) {  // rows beyond the variables are identity: nothing to eliminate (uniform branch)
+      const double dj = readlane_f64(col[j], j);
+      if (!(dj > 0.) || !isfinite(dj)) ok = false;
+      const double dinv = fast_rsqrt(dj);
+      const double lkj = c > j ? col[j] * dinv : 0.;  // L[c][j] for the columns still open
+      const double yj = readlane_f64(y, j) * dinv;
+      if (c == j) { mydinv = dinv; yown = yj; }
 #pragma unroll
-    for (int i = j + 1; i < NR; ++i) {
-      const double lij = readlane_f64(col[i], j) * dinv;
-      col[i] -= lij * lkj;
+      for (int i = j + 1; i < NR; ++i) {
+        const double lij = readlane_f64(col[i], j) * dinv;
+        col[i] -= lij * lkj;
+      }
+      y -= yj * lkj;
     }
-    y -= yj * lkj;
   }
   double s = 0.;
   x_own = 0.;
 #pragma unroll
   for (int j = NR - 1; j >= 0; --j) {
-    const double xj = readlane_f64((yown - s) * mydinv, j);
-    if (c == j) x_own = xj;
-    s += (c < j ? col[j] * mydinv : 0.) * xj;
+    if (j < nv) {
+      const double xj = readlane_f64((yown - s) * mydinv, j);
+      if (c == j) x_own = xj;
+      s += (c < j ? col[j] * mydinv : 0.) * xj;
+    }
   }
   return ok;
 }
@@ -317,8 +330,19 @@ __device__ void chol_solve_w(const double* Lp, int nf, double* x, int nrhs, int 
   }
 }
 
+#ifdef CTR_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP(slot) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    if (wave == 0 && lane == 0) atomicAdd(&g_stamps[slot], now_ - t_prev_); t_prev_ = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
 template <int ND, bool ISO, int NT, int W>
 __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
+#ifdef CTR_STAMPS
+  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#endif
   using SM = SmemB<NT, W>;
   constexpr int NP = 2 + ND + (ISO ? 1 : ND);
   constexpr int NSZ = ISO ? 1 : ND;
@@ -365,18 +389,23 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
   };
   // derived constants of every feature at vv: [0] signal [1..3] centre
   // [4..6] 1/size^2 [7..9] 2/size^2 [10..12] -2/size^3   (wave 0)
-  auto fill_fpar = [&](const double* vv) {
+  bool size_is_var = false;
+#pragma unroll
+  for (int kk = 2 + ND; kk < NP; ++kk) size_is_var = size_is_var || L.var_of[kk] >= 0;
+  auto fill_fpar = [&](const double* vv, bool sizes) {
     for (int i = lane; i < n; i += WAVE) {
       double* f = fpar + i * FP;
       f[0] = par(vv, i, 1);
 #pragma unroll
       for (int a = 0; a < ND; ++a) {
         f[1 + a] = par(vv, i, 2 + a);
-        const double sz = par(vv, i, ISO ? 2 + ND : 2 + ND + a);
-        const double s2 = sz * sz;
-        f[4 + a] = 1. / s2;
-        f[7 + a] = 2. / s2;
-        f[10 + a] = -2. / (s2 * sz);
+        if (sizes) {  // three f64 divisions per axis: only when a size actually changed
+          const double sz = par(vv, i, ISO ? 2 + ND : 2 + ND + a);
+          const double s2 = sz * sz;
+          f[4 + a] = 1. / s2;
+          f[7 + a] = 2. / s2;
+          f[10 + a] = -2. / (s2 * sz);
+        }
       }
     }
   };
@@ -528,7 +557,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
       for (int a = 0; a < ND; ++a) { ctl[1 + a] = origin[a]; ctl[4 + a] = wshape[a]; }
     }
     wsync();
-    fill_fpar(vt);
+    fill_fpar(vt, size_is_var || round == 0);
     it = 0;
     return BP_EVAL_INIT;
   };
@@ -554,6 +583,8 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
       const int npix = (ND == 3 ? wshape[0] : 1) * w1 * w2;
       const int bgvar = L.var_of[0];
       const double bg = par(vt, 0, 0);
+      const float inv_w2 = 1.f / (float)w2, inv_w1 = 1.f / (float)w1;
+      const bool big_window = npix >= (1 << 21);
 #pragma unroll
       for (int t = 0; t < SM::NTILE; ++t) acc[t] = v4d{0., 0., 0., 0.};
       double* row = myrows + lane * SM::RS;
@@ -563,9 +594,13 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         int idx[ND];
         size_t off;
         {
-          const int x = q % w2, t = q / w2;
+          // q / w2 through the float reciprocal: exact for q < 2^21 (q + 0.5 is never
+          // within 0.5 / w2 of a multiple of w2, far above the float rounding error)
+          const int t = big_window ? q / w2 : (int)(((float)q + 0.5f) * inv_w2);
+          const int x = q - t * w2;
           if (ND == 3) {
-            const int y = t % w1, z = t / w1;
+            const int z = big_window ? t / w1 : (int)(((float)t + 0.5f) * inv_w1);
+            const int y = t - z * w1;
             idx[0] = z; idx[1] = y; idx[ND - 1] = x;
             off = ((size_t)(z + origin[0]) * fshape[1] + (y + origin[1])) * fshape[ND - 1] + (x + origin[ND - 1]);
           } else {
@@ -670,7 +705,9 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         if (lane == 0) { part[2 * wave] = Sloc; part[2 * wave + 1] = (double)P; }
       }
     }
+    STAMP(0);
     if (W > 1) __syncthreads();
+    STAMP(1);
 
     if (wave == 0) {
       // ---- wave 0: sum, accept / reject, next step ---------------------------------------
@@ -742,6 +779,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         S = St;
         wsync();
       }
+      STAMP(2);
       if (!failed && it >= maxiter) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
       bool converged = false;
       if (!failed) {
@@ -763,6 +801,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           nf += __popcll(bal);
         }
         wsync();
+        STAMP(3);
         bool ok_step = true;
         bool have_dl = false;
         if (nf == 0) {
@@ -853,6 +892,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             }
           }
         }
+        STAMP(4);
         if (!converged) {
           if (!ok_step) {
             mu *= nu; nu *= 2.; last_acc = false;
@@ -908,6 +948,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           }
         }
       }
+      STAMP(5);
       if (failed) next = BP_FINISH;
       if (converged) {
         // end of a round: vect_to_params and the shift test (refine.py:379-388)
@@ -942,11 +983,13 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           next = begin_round();
         }
       } else if (next == BP_EVAL_TRIAL) {
-        fill_fpar(vt);
+        fill_fpar(vt, size_is_var);
       }
+      STAMP(6);
       if (lane == 0) ctl[0] = next;
     }
     __syncthreads();
+    STAMP(7);
   }
 
   if (wave == 0) {
@@ -1170,6 +1213,7 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
       const int w_last = wshape[ND - 1];
       const float inv_w2 = 1.f / (float)w_last;
       const float inv_w1 = ND == 3 ? 1.f / (float)wshape[1] : 1.f;
+      const bool big_window = npix >= (1 << 21);
       const double bg = vt[0];
       for (int base = 0; __any(base < npix_here); base += SG) {
         const int q = base + sub;
@@ -1177,10 +1221,10 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
           int idx[ND];
           size_t off;
           {
-            const int t = (int)(((float)q + 0.5f) * inv_w2);
+            const int t = big_window ? q / w_last : (int)(((float)q + 0.5f) * inv_w2);
             const int x = q - t * w_last;
             if (ND == 3) {
-              const int z = (int)(((float)t + 0.5f) * inv_w1);
+              const int z = big_window ? t / wshape[1] : (int)(((float)t + 0.5f) * inv_w1);
               const int y = t - z * wshape[1];
               idx[0] = z; idx[1] = y; idx[ND - 1] = x;
               off = ((size_t)(z + origin[0]) * fshape[1] + (y + origin[1])) * fshape[ND - 1] + (x + origin[ND - 1]);
@@ -1537,7 +1581,7 @@ __global__ void frame_max_decode_kernel(const unsigned long long* enc, double* o
 typedef void (*kernel_fn)(const KArgs);
 typedef void (*small_fn)(const KArgs, int*);
 
-template <int NT> struct WavesFor { static constexpr int value = NT <= 3 ? 4 : (NT <= 6 ? 2 : 1); };
+template <int NT> struct WavesFor { static constexpr int value = NT == 2 ? 8 : (NT <= 3 ? 4 : (NT <= 6 ? 2 : 1)); };
 
 template <int ND, bool ISO, int NT>
 void fill_one(kernel_fn* t, size_t* bytes, int* threads) {
@@ -1944,6 +1988,17 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
   h->ev_valid = true;
   return CTR_OK;
 }
+
+#ifdef CTR_STAMPS
+int ctr_debug_stamps(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 
 int ctr_synchronize(ctr_handle* h, void* hip_stream) {
   if (!h) return CTR_ERR_INVALID;
