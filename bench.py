@@ -33,6 +33,14 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--frames', type=int, default=256, help='frames per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg3', 'cfg5'],
+                    help="cfg2 is the contract's workload; cfg3 (3D stacks, --frames = stacks) and "
+                         "cfg5 (dense clusters + constrained dimers) are recorded in DESIGN.md")
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                         "the N > 1 code path on a one-GPU box)")
+    ap.add_argument('--single-device', action='store_true',
+                    help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -66,17 +74,37 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    coll_dev = 'cuda' if args.backend == 'nccl' else 'cpu'   # where collective buffers live
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
 
     # ---- this rank's shard: frames [rank*F, (rank+1)*F) of the video --------------
-    frames, f0, truth, opts = workloads.cfg2(args.frames, first_seed=rank * args.frames)
+    extra = {}
+    if args.workload == 'cfg2':
+        frames, f0, truth, opts = workloads.cfg2(args.frames, first_seed=rank * args.frames)
+        wl_text = ("cfg2: %d frames/GPU of 512x512 uint8, 200 Gaussians/frame, size 3 (radius of "
+                   "gyration), diameter 13, Poisson noise 10, isotropic Gaussian model, default "
+                   "param modes" % args.frames)
+    elif args.workload == 'cfg3':
+        frames, f0, truth, opts = workloads.cfg3(args.frames, first_seed=rank * args.frames)
+        wl_text = ("cfg3: %d stacks/GPU of 64x128x128 uint8, 500 Gaussians/stack, size (2,4,4), "
+                   "diameter (9,17,17), anisotropic Gaussian model, default param modes" % args.frames)
+    else:
+        frames, f0, truth, opts = workloads.cfg5(args.frames, first_seed=rank * args.frames)
+        extra['constraints'] = cta.constraints.dimer(6., 2)
+        wl_text = ("cfg5: %d frames/GPU of 512x512 uint8, 36 compact clusters of 2/8-16 Gaussians, "
+                   "size 3, diameter 13, dimers constrained to 2*size" % args.frames)
     reader = cta.ArrayReader(frames)
     t0 = time.perf_counter()
-    prep = cta.prepare_batch(f0, reader, opts['diameter'])
+    prep = cta.prepare_batch(f0, reader, opts['diameter'], **extra)
     t_host_prep = time.perf_counter() - t0
     db = DeviceBatch(prep.problem, prep.batch, device=local_rank)
     n_fits = prep.batch.n_clusters
@@ -85,20 +113,21 @@ def main():
 
     gather_buf = None
     if world > 1:
-        counts = [torch.zeros(1, dtype=torch.int64, device='cuda') for _ in range(world)]
-        dist.all_gather(counts, torch.tensor([n_feat], dtype=torch.int64, device='cuda'))
+        counts = [torch.zeros(1, dtype=torch.int64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([n_feat], dtype=torch.int64, device=coll_dev))
         counts = [int(c.item()) for c in counts]
         width = prep.batch.params.shape[1] + 1
         pad = max(counts)
         if rank == 0:
-            gather_buf = [torch.empty((pad, width), dtype=torch.float64, device='cuda')
+            gather_buf = [torch.empty((pad, width), dtype=torch.float64, device=coll_dev)
                           for _ in range(world)]
-        send = torch.zeros((pad, width), dtype=torch.float64, device='cuda')
+        send = torch.zeros((pad, width), dtype=torch.float64, device=coll_dev)
 
     def step():
         db.run(stream)
         if world > 1:
-            send[:n_feat] = db.results_tensor()
+            # the only exchange of the path: result rows of every rank -> rank 0
+            send[:n_feat] = db.results_tensor().to(coll_dev)
             dist.gather(send, gather_buf, dst=0)
 
     def fence():
@@ -123,8 +152,8 @@ def main():
         rf_ms.append(b)
     fence()
 
-    t_all = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-    fits_all = torch.tensor([float(n_fits)], dtype=torch.float64, device='cuda')
+    t_all = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    fits_all = torch.tensor([float(n_fits)], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
         dist.all_reduce(fits_all, op=dist.ReduceOp.SUM)
@@ -144,22 +173,26 @@ def main():
         rf = float(np.median(rf_ms)) * 1e-3
         fm = float(np.median(fm_ms)) * 1e-3
         peak = 8000.0
+        traffic = None
+        tf = os.path.join(ROOT, 'profiles', 'traffic_cfg2.json')
+        if args.workload == 'cfg2' and args.frames == 256 and os.path.exists(tf):
+            # HBM bytes of the refine kernels from the committed rocprofv3 PMC passes
+            # (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction); see the file
+            traffic = json.load(open(tf))['refine_kernels']['bytes_corrected']
         result = {
             "metric": "cluster-fits/sec", "value": value, "unit": "cluster-fits/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "cfg2: %d frames/GPU of 512x512 uint8, 200 Gaussians/frame, "
-                                   "size 3 (radius of gyration), diameter 13, Poisson noise 10, "
-                                   "isotropic Gaussian model, default param modes" % args.frames,
+            "config": {"workload": wl_text,
                        "frames_per_gpu": args.frames, "cluster_fits_per_gpu": n_fits,
                        "features_per_gpu": n_feat, "parallelism": "frames sharded, %d rank(s)" % world},
             "features_per_s": value * n_feat / max(n_fits, 1),
             "failed_clusters": n_fail,
             "mean_solver_iterations": mean_iters,
-            "roofline": {"bound": "hbm", "kernel": "refine_kernel<2,iso,NT=1> (all bins)",
+            "roofline": {"bound": "hbm", "kernel": "refine stage: refine_small_kernel<2,1|2> + refine_block_kernel<2,iso,NT,W> (concurrent streams)",
                          "achieved": alg_bytes / rf / 1e9, "peak": peak, "unit": "GB/s",
-                         "frac": alg_bytes / rf / 1e9 / peak, "traffic": None,
+                         "frac": alg_bytes / rf / 1e9 / peak, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": rf * 1e3},
             "roofline_frame_max": {"bound": "hbm", "kernel": "frame_max_kernel",
                                    "achieved": hb.frames.nbytes / fm / 1e9, "peak": peak,
@@ -172,7 +205,7 @@ def main():
             # the oracle overwrote the host outputs with its own: compare with the GPU's
             both = (hb.status == 0) & (gpu_status == 0)
             result["status_equal_oracle"] = bool((hb.status == gpu_status).all())
-            pos = slice(2, 4)
+            pos = slice(2, 2 + frames.ndim - 1)
             ok_rows = np.repeat(both, np.diff(hb.feat_offset))
             dpos = (gpu_out[:, pos] - hb.params_out[:, pos])[ok_rows]
             result["parity_vs_oracle_px"] = {"rmse": float(np.sqrt(np.mean(dpos ** 2))),
