@@ -39,6 +39,8 @@ def parse():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                          "the N > 1 code path on a one-GPU box)")
+    ap.add_argument('--features', type=int, default=None,
+                    help="features per frame/stack (default: the workload's own)")
     ap.add_argument('--single-device', action='store_true',
                     help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
@@ -94,9 +96,12 @@ def main():
                    "gyration), diameter 13, Poisson noise 10, isotropic Gaussian model, default "
                    "param modes" % args.frames)
     elif args.workload == 'cfg3':
-        frames, f0, truth, opts = workloads.cfg3(args.frames, first_seed=rank * args.frames)
-        wl_text = ("cfg3: %d stacks/GPU of 64x128x128 uint8, 500 Gaussians/stack, size (2,4,4), "
-                   "diameter (9,17,17), anisotropic Gaussian model, default param modes" % args.frames)
+        nfeat = args.features or 500
+        frames, f0, truth, opts = workloads.cfg3(args.frames, first_seed=rank * args.frames,
+                                                 n_features=nfeat)
+        wl_text = ("cfg3: %d stacks/GPU of 64x128x128 uint8, %d Gaussians/stack, size (2,4,4), "
+                   "diameter (9,17,17), anisotropic Gaussian model, default param modes"
+                   % (args.frames, nfeat))
     else:
         frames, f0, truth, opts = workloads.cfg5(args.frames, first_seed=rank * args.frames)
         extra['constraints'] = cta.constraints.dimer(6., 2)

@@ -1639,7 +1639,8 @@ struct ctr_handle {
   size_t smem_bytes[2][2][MAXNT];
   int block_threads[2][2][MAXNT];
   bool attr_set[2][2][MAXNT] = {};
-  small_fn small_table[2][2][2];  // [ndim-2][iso][nf-1]
+  small_fn small_table[2][2][2];  // [ndim-2][iso][nf-1]; singles with 16 lanes per cluster
+  small_fn small_wide1[2][2];     // singles with 64 lanes per cluster (large windows)
   hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {nullptr, nullptr, nullptr};
   int* d_counter = nullptr;       // work counters of the small-kernel launches
@@ -1783,6 +1784,10 @@ int ctr_create(ctr_handle** out, int device) {
   bool evok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
   for (auto& ev : h->ev_join) evok = evok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
   if (!evok || hipMalloc((void**)&h->d_counter, sizeof(int) * 8) != hipSuccess) { delete h; return fail(nullptr, CTR_ERR_DEVICE, "cannot create events / counters"); }
+  h->small_wide1[0][1] = refine_small_kernel<2, 1, true, 64>;
+  h->small_wide1[0][0] = refine_small_kernel<2, 1, false, 64>;
+  h->small_wide1[1][1] = refine_small_kernel<3, 1, true, 64>;
+  h->small_wide1[1][0] = refine_small_kernel<3, 1, false, 64>;
   h->small_table[0][1][0] = refine_small_kernel<2, 1, true, 16>;
   h->small_table[0][1][1] = refine_small_kernel<2, 2, true, 64>;
   h->small_table[0][0][0] = refine_small_kernel<2, 1, false, 16>;
@@ -1974,9 +1979,15 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     HIP_TRY(h, hipMemsetAsync(counter, 0, sizeof(int), st));
     k.order = plan->d_order + plan->bin_begin[bin];
     k.n_bin = (int32_t)cnt;
-    int64_t waves = nf == 1 ? (cnt + 3) / 4 : cnt;  // singles: 4 clusters per wave; pairs: 1
+    // lanes per cluster by the size of a single-feature window: 16 (four clusters per
+    // wave) while a window is a few passes, 64 once it is thousands of pixels (3D)
+    int64_t vol = 1;
+    for (int a = 0; a < p.ndim; ++a) vol *= 2 * (int64_t)p.radius[a] + 1;
+    const bool wide = nf == 2 || vol > 600;
+    small_fn fn = nf == 2 ? h->small_table[di][ii][1] : (wide ? h->small_wide1[di][ii] : h->small_table[di][ii][0]);
+    int64_t waves = wide ? cnt : (cnt + 3) / 4;
     if (waves > 8192) waves = 8192;
-    hipLaunchKernelGGL(h->small_table[di][ii][nf - 1], dim3((unsigned)waves), dim3(WAVE), 0, st, k, counter);
+    hipLaunchKernelGGL(fn, dim3((unsigned)waves), dim3(WAVE), 0, st, k, counter);
   }
   for (int j = 0; j < NSIDE; ++j)
     if (used[j]) {
