@@ -46,6 +46,9 @@ def parse():
     return ap.parse_args()
 
 
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+
+
 def cpu_baseline(problem, host_batch):
     """The C oracle (oracle/ctr_oracle.c: same algorithm as the engine, scalar
     C + OpenMP over clusters) timed on the host cores of this box."""
@@ -206,24 +209,46 @@ def main():
             "host_prepare_s": t_host_prep,
         }
         if world == 1 and not args.no_cpu_baseline:
+            pos = slice(2, 2 + frames.ndim - 1)
+            # (a) the reference's own algorithm restated (NumPy objective + SciPy SLSQP,
+            #     oracle/ref_numpy.py), one thread, on a bounded sample of the same workload
+            import ref_numpy
+            n_sample_frames = max(1, min(args.frames, 8 if args.workload == 'cfg2' else 2))
+            sample = np.flatnonzero(hb.frame_index < n_sample_frames)
+            t0 = time.perf_counter()
+            ref_numpy.run_batch(prep.problem, hb, clusters=sample)
+            dt_py = time.perf_counter() - t0
+            rows = np.concatenate([np.arange(hb.feat_offset[c], hb.feat_offset[c + 1]) for c in sample])
+            ok_c = (hb.status[sample] == 0) & (gpu_status[sample] == 0)
+            ok_rows = np.repeat(ok_c, np.diff(hb.feat_offset)[sample])
+            d = (gpu_out[rows][:, pos] - hb.params_out[rows][:, pos])[ok_rows]
+            result["parity_vs_scipy_slsqp_px"] = {
+                "rmse": float(np.sqrt(np.mean(d ** 2))), "max": float(np.abs(d).max()),
+                "clusters": int(len(sample)),
+                "failed_here_not_there": int(((gpu_status[sample] != 0) & (hb.status[sample] == 0)).sum()),
+                "failed_there_not_here": int(((gpu_status[sample] == 0) & (hb.status[sample] != 0)).sum()),
+                "note": "engine vs the reference algorithm with its default SLSQP tol=1e-6 "
+                        "(north_star: <= 1e-3 px)"}
+            # (b) the C oracle (same LM as the engine, scalar C + OpenMP over clusters), full workload
             base = cpu_baseline(prep.problem, prep.batch)
-            # the oracle overwrote the host outputs with its own: compare with the GPU's
             both = (hb.status == 0) & (gpu_status == 0)
             result["status_equal_oracle"] = bool((hb.status == gpu_status).all())
-            pos = slice(2, 2 + frames.ndim - 1)
             ok_rows = np.repeat(both, np.diff(hb.feat_offset))
             dpos = (gpu_out[:, pos] - hb.params_out[:, pos])[ok_rows]
             result["parity_vs_oracle_px"] = {"rmse": float(np.sqrt(np.mean(dpos ** 2))),
                                              "max": float(np.abs(dpos).max())}
             result["cpu_baseline"] = {
+                "value": len(sample) / dt_py, "unit": "cluster-fits/s", "cores": 1, "kind": "port",
+                "sample": "the first %d frames of the workload (%d cluster-fits, %.1f s): "
+                          "oracle/ref_numpy.py = the reference's algorithm (NumPy objective + "
+                          "SciPy SLSQP tol=1e-6, Python loop per cluster)" % (
+                              n_sample_frames, len(sample), dt_py),
+                "reference_python_fits_per_s_survey": 109.0}
+            result["cpu_baseline_native_lm"] = {
                 "value": base['all'][0], "unit": "cluster-fits/s", "cores": base['all'][1],
-                "kind": "port", "sample": "the full workload of one GPU (%d cluster-fits), "
-                "C oracle, OpenMP over clusters" % n_fits,
-                "one_thread_value": base['one'][0],
-                "reference_python_fits_per_s": 109.0,
-                "reference_python_note": "reference refine_leastsq (SciPy SLSQP), 1 thread, "
-                                         "measured in the survey container (BASELINE.md section 2); "
-                                         "it cannot run on the GPU box"}
+                "kind": "port", "one_thread_value": base['one'][0],
+                "sample": "the full workload of one GPU (%d cluster-fits): oracle/ctr_oracle.c = "
+                          "the engine's bounded LM in scalar C, OpenMP over clusters" % n_fits}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
