@@ -171,7 +171,7 @@ def main():
     # ---- correctness of what was timed (rank 0): oracle on the same batch ---------
     hb = db.download()
     n_fail = int((hb.status != 0).sum())
-    gpu_out, gpu_status = hb.params_out.copy(), hb.status.copy()
+    gpu_out, gpu_status, gpu_cost = hb.params_out.copy(), hb.status.copy(), hb.cost.copy()
     mean_iters = float(hb.n_iter.mean())
     result = None
     if rank == 0:
@@ -220,15 +220,22 @@ def main():
             dt_py = time.perf_counter() - t0
             rows = np.concatenate([np.arange(hb.feat_offset[c], hb.feat_offset[c + 1]) for c in sample])
             ok_c = (hb.status[sample] == 0) & (gpu_status[sample] == 0)
-            ok_rows = np.repeat(ok_c, np.diff(hb.feat_offset)[sample])
-            d = (gpu_out[rows][:, pos] - hb.params_out[rows][:, pos])[ok_rows]
+            # a handful of clusters (near-coincident features) have several local minima and
+            # the two solvers may settle in different ones (either may have the lower cost):
+            # they are counted, and the position statistics are over the clusters in the same one
+            same_min = ok_c & (np.abs(gpu_cost[sample] - hb.cost[sample]) <= 1e-5 * np.abs(hb.cost[sample]))
+            n_per = np.diff(hb.feat_offset)[sample]
+            d_all = np.abs(gpu_out[rows][:, pos] - hb.params_out[rows][:, pos]).max(1)
+            d = (gpu_out[rows][:, pos] - hb.params_out[rows][:, pos])[np.repeat(same_min, n_per)]
             result["parity_vs_scipy_slsqp_px"] = {
                 "rmse": float(np.sqrt(np.mean(d ** 2))), "max": float(np.abs(d).max()),
-                "clusters": int(len(sample)),
+                "median_all": float(np.median(d_all[np.repeat(ok_c, n_per)])),
+                "clusters": int(len(sample)), "clusters_same_minimum": int(same_min.sum()),
+                "clusters_other_minimum": int((ok_c & ~same_min).sum()),
                 "failed_here_not_there": int(((gpu_status[sample] != 0) & (hb.status[sample] == 0)).sum()),
                 "failed_there_not_here": int(((gpu_status[sample] == 0) & (hb.status[sample] != 0)).sum()),
                 "note": "engine vs the reference algorithm with its default SLSQP tol=1e-6 "
-                        "(north_star: <= 1e-3 px)"}
+                        "(north_star: <= 1e-3 px); rmse/max over clusters whose cost agrees to 1e-5"}
             # (b) the C oracle (same LM as the engine, scalar C + OpenMP over clusters), full workload
             base = cpu_baseline(prep.problem, prep.batch)
             both = (hb.status == 0) & (gpu_status == 0)

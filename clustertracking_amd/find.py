@@ -59,25 +59,50 @@ def find_iter(f, separation, pos_columns=None, t_column='frame'):
         yield frame_no, result
 
 
+def label_frames(pos, frames, separation):
+    """Cluster ids and sizes for a whole table at once (NumPy only).
+
+    pos [N, ndim], frames [N]; returns (order, ids, sizes) where ``order`` is
+    the stable frame-sorted row order of find_clusters' output and ids/sizes
+    are aligned with it.  Same labels as running :func:`label_points` frame by
+    frame with the reference's running id offset (find.py:120-128)."""
+    pos = np.asarray(pos, dtype=np.float64)
+    frames = np.asarray(frames)
+    order = np.argsort(frames, kind='stable')
+    fs = frames[order]
+    n = len(order)
+    ids = np.empty(n, dtype=np.int64)
+    sizes = np.empty(n, dtype=np.int64)
+    if n == 0:
+        return order, ids, sizes
+    starts = np.flatnonzero(np.r_[True, fs[1:] != fs[:-1]])
+    stops = np.r_[starts[1:], n]
+    scaled = pos[order] / separation
+    next_id = 0
+    for a, b in zip(starts, stops):
+        lab, siz = label_points(scaled[a:b], 1.)
+        ids[a:b] = lab + next_id
+        sizes[a:b] = siz
+        next_id = ids[a:b].max() + 1
+    return order, ids, sizes
+
+
 def find_clusters(f, separation, pos_columns=None, t_column='frame'):
     """Copy of ``f`` (rows grouped by frame) with ``cluster`` and
-    ``cluster_size`` columns (reference find.py:132-163)."""
+    ``cluster_size`` columns (reference find.py:132-163).  One pass over NumPy
+    arrays instead of a DataFrame copy per frame; same rows, order and labels."""
     if pos_columns is None:
         pos_columns = guess_pos_columns(f)
     separation = np.array(validate_tuple(separation, len(pos_columns)),
                           dtype=np.float64)
-    remove_t = t_column not in f
-    if remove_t:
-        f[t_column] = 0
-    try:
-        parts = [x[1] for x in find_iter(f, separation, pos_columns, t_column)]
-        if parts:
-            result = pd.concat(parts)
-        else:  # empty table (the reference raises ValueError from pd.concat here)
-            result = f.copy()
-            result['cluster'] = np.zeros(0, dtype=np.int64)
-            result['cluster_size'] = np.zeros(0, dtype=np.int64)
-    finally:
-        if remove_t:
-            del f[t_column]
+    if t_column in f:
+        frames = f[t_column].values
+    else:
+        frames = np.zeros(len(f), dtype=np.int64)
+    order, ids, sizes = label_frames(f[pos_columns].values, frames, separation)
+    result = f.iloc[order].copy()
+    if t_column not in f:
+        result[t_column] = 0   # the reference's output carries the temporary column (find.py:149-157)
+    result['cluster'] = ids
+    result['cluster_size'] = sizes
     return result

@@ -123,10 +123,11 @@ class FitFunctions(object):
         params = np.asarray(params, dtype=np.float64)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            low = np.nanmax([params - b_diff[0], params * (1 - b_rel[0])], axis=0)
+            # np.nanmax([a, b], axis=0) == np.fmax(a, b) (NaN only where both are NaN)
+            low = np.fmax(params - b_diff[0], params * (1 - b_rel[0]))
             low = np.fmax(low, b_abs[0])
             low[np.isnan(low)] = -np.inf
-            high = np.nanmin([params + b_diff[1], params * (1 + b_rel[1])], axis=0)
+            high = np.fmin(params + b_diff[1], params * (1 + b_rel[1]))
             high = np.fmin(high, b_abs[1])
             high[np.isnan(high)] = np.inf
         return low, high
