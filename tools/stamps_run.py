@@ -9,8 +9,16 @@ from clustertracking_amd import workloads, _abi, _lib
 
 lo_n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 hi_n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-frames, f0, truth, opts = workloads.cfg2(256, 0)
-prep = cta.prepare_batch(f0, cta.ArrayReader(frames), 13)
+wl = os.environ.get('WL', 'cfg2')
+if wl == 'cfg2':
+    frames, f0, truth, opts = workloads.cfg2(256, 0)
+    prep = cta.prepare_batch(f0, cta.ArrayReader(frames), 13)
+elif wl == 'cfg5':
+    frames, f0, truth, opts = workloads.cfg5(64, 0)
+    prep = cta.prepare_batch(f0, cta.ArrayReader(frames), 13, constraints=cta.constraints.dimer(6., 2))
+else:
+    frames, f0, truth, opts = workloads.cfg3(64, 0, n_features=40)
+    prep = cta.prepare_batch(f0, cta.ArrayReader(frames), opts['diameter'])
 hb = prep.batch
 sz = np.diff(hb.feat_offset)
 sel = np.flatnonzero((sz >= lo_n) & (sz <= hi_n))
