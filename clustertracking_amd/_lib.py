@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get('CTREFINE_LIB') or os.path.join(_HERE, 'csrc', 'libctr
 EXPORTS = ('ctr_abi_version', 'ctr_create', 'ctr_destroy', 'ctr_last_error',
            'ctr_validate_problem', 'ctr_cluster_n_vars', 'ctr_refine_batch',
            'ctr_plan_create', 'ctr_plan_destroy', 'ctr_refine_batch_device',
-           'ctr_frame_max_device', 'ctr_synchronize', 'ctr_last_kernel_ms')
+           'ctr_frame_max_device', 'ctr_synchronize', 'ctr_last_kernel_ms',
+           'ctr_find_clusters')
 
 _lib = None
 _lock = threading.Lock()
@@ -90,6 +91,9 @@ def load():
                                              C.c_int64, C.c_int64, C.c_void_p,
                                              C.c_void_p]
         lib.ctr_frame_max_device.restype = C.c_int
+        lib.ctr_find_clusters.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ctr_find_clusters.restype = C.c_int
         lib.ctr_synchronize.argtypes = [C.c_void_p, C.c_void_p]
         lib.ctr_synchronize.restype = C.c_int
         lib.ctr_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_double), P(C.c_double)]
@@ -158,6 +162,22 @@ class Engine(object):
         self._check(self._lib.ctr_frame_max_device(
             self._h, C.c_void_p(frames_ptr), dtype_code, n_frames, frame_elems,
             C.c_void_p(out_ptr), C.c_void_p(stream or 0)), 'ctr_frame_max_device')
+
+    def find_clusters(self, pos, frame_offset, separation):
+        """Labels (smallest row index of the cluster) and sizes for a frame-sorted
+        position table; ``ctr_find_clusters``."""
+        import numpy as np
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        off = np.ascontiguousarray(frame_offset, dtype=np.int32)
+        sep = np.ascontiguousarray(separation, dtype=np.float64)
+        n, nd = pos.shape
+        labels = np.empty(n, dtype=np.int32)
+        sizes = np.empty(n, dtype=np.int32)
+        self._check(self._lib.ctr_find_clusters(self._h, nd, pos.ctypes.data, off.ctypes.data,
+                                                len(off) - 1, sep.ctypes.data,
+                                                labels.ctypes.data, sizes.ctypes.data),
+                    'ctr_find_clusters')
+        return labels, sizes
 
     def synchronize(self, stream=None):
         self._check(self._lib.ctr_synchronize(self._h, C.c_void_p(stream or 0)),

@@ -226,8 +226,10 @@ __device__ __forceinline__ bool column_solve(const double* Mp, int nv, double mu
       if (c == j) { mydinv = dinv; yown = yj; }
 #pragma unroll
       for (int i = j + 1; i < NR; ++i) {
-        const double lij = readlane_f64(col[i], j) * dinv;
-        col[i] -= lij * lkj;
+        if (i < nv) {  // uniform: the rows beyond the variables stay identity
+          const double lij = readlane_f64(col[i], j) * dinv;
+          col[i] -= lij * lkj;
+        }
       }
       y -= yj * lkj;
     }
@@ -1491,6 +1493,65 @@ __global__ void mark_kernel(const KArgs k, int code) {
   k.n_iter[cl] = 0;
 }
 
+
+// ---- cluster labelling (reference find.py:72-93): which features are fitted together ----
+// Features of one frame closer than `separation` (per-axis scaled Euclidean distance <= 1,
+// the criterion of cKDTree(pos / separation).query_pairs(1)) share a cluster.  One workgroup
+// per frame; label propagation to the smallest row index of the cluster until nothing
+// changes (bounded by the number of features of the frame).  The label is canonical (the
+// reference's ids depend on Python set order); the PARTITION is the reference's.
+constexpr int FC_THREADS = 256;
+
+template <int ND>
+__global__ void __launch_bounds__(FC_THREADS) find_clusters_kernel(const double* __restrict__ pos,
+                                                                   const int32_t* __restrict__ frame_offset,
+                                                                   double s0, double s1, double s2,
+                                                                   double* __restrict__ spos, int32_t* label,
+                                                                   int32_t* __restrict__ count,
+                                                                   int32_t* __restrict__ size_out) {
+  const int f = blockIdx.x;
+  const int r0 = frame_offset[f], r1 = frame_offset[f + 1];
+  const double sep[3] = {s0, s1, s2};
+  for (int i = r0 + threadIdx.x; i < r1; i += FC_THREADS) {
+#pragma unroll
+    for (int a = 0; a < ND; ++a) spos[(size_t)i * ND + a] = pos[(size_t)i * ND + a] / sep[a];
+    label[i] = i;
+  }
+  __syncthreads();
+  for (int sweep = 0; sweep <= r1 - r0; ++sweep) {
+    bool changed = false;
+    for (int i = r0 + threadIdx.x; i < r1; i += FC_THREADS) {
+      double p[ND];
+#pragma unroll
+      for (int a = 0; a < ND; ++a) p[a] = spos[(size_t)i * ND + a];
+      const int mine = __hip_atomic_load(&label[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      int m = mine;
+      for (int j = r0; j < r1; ++j) {
+        double d2 = 0.;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+          const double d = p[a] - spos[(size_t)j * ND + a];
+          d2 += d * d;
+        }
+        if (d2 <= 1.) {
+          const int lj = __hip_atomic_load(&label[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          m = lj < m ? lj : m;
+        }
+      }
+      if (m < mine) {
+        __hip_atomic_store(&label[i], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        changed = true;
+      }
+    }
+    if (!__syncthreads_or(changed ? 1 : 0)) break;
+  }
+  // labels of this frame are final: root = smallest row index; count members, then sizes
+  for (int i = r0 + threadIdx.x; i < r1; i += FC_THREADS) atomicAdd(&count[label[i]], 1);
+  __syncthreads();
+  for (int i = r0 + threadIdx.x; i < r1; i += FC_THREADS)
+    size_out[i] = __hip_atomic_load(&count[label[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- per-frame maximum (the norm of refine.py:354) --------------------------------
 // Streams the frame block once: 16 B per lane per load, one ordered-u64 atomicMax
 // per workgroup.  HBM-bound.
@@ -2010,6 +2071,55 @@ int ctr_debug_stamps(unsigned long long* out16, int reset) {
   return 0;
 }
 #endif
+
+
+int ctr_find_clusters(ctr_handle* h, int32_t ndim, const double* pos, const int32_t* frame_offset,
+                      int64_t n_frames, const double* separation, int32_t* label_out, int32_t* size_out) {
+  if (!h || !pos || !frame_offset || !separation || !label_out || !size_out) return CTR_ERR_INVALID;
+  if (ndim != 2 && ndim != 3) return fail(h, CTR_ERR_INVALID, "ndim must be 2 or 3");
+  if (n_frames < 0 || n_frames > 0x7fffffffLL) return fail(h, CTR_ERR_INVALID, "bad frame count");
+  if (n_frames == 0) return CTR_OK;
+  const int64_t N = frame_offset[n_frames];
+  if (frame_offset[0] != 0 || N < 0) return fail(h, CTR_ERR_INVALID, "frame_offset must run from 0 to the row count");
+  for (int64_t f = 0; f < n_frames; ++f)
+    if (frame_offset[f + 1] < frame_offset[f]) return fail(h, CTR_ERR_INVALID, "frame_offset must be non-decreasing");
+  for (int a = 0; a < ndim; ++a)
+    if (!(separation[a] > 0.)) return fail(h, CTR_ERR_INVALID, "separation must be positive");
+  if (N == 0) return CTR_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t sz_pos = al(sizeof(double) * (size_t)N * ndim), sz_fo = al(sizeof(int32_t) * (size_t)(n_frames + 1));
+  const size_t sz_i = al(sizeof(int32_t) * (size_t)N);
+  const size_t total = 2 * sz_pos + sz_fo + 3 * sz_i;
+  if (total > h->d_buf_bytes) {
+    if (h->d_buf) { (void)hipFree(h->d_buf); h->d_buf = nullptr; h->d_buf_bytes = 0; }
+    if (hipMalloc(&h->d_buf, total) != hipSuccess) return fail(h, CTR_ERR_NOMEM, "cannot allocate device memory");
+    h->d_buf_bytes = total;
+  }
+  char* q = (char*)h->d_buf;
+  double* d_pos = (double*)q; q += sz_pos;
+  double* d_spos = (double*)q; q += sz_pos;
+  int32_t* d_fo = (int32_t*)q; q += sz_fo;
+  int32_t* d_label = (int32_t*)q; q += sz_i;
+  int32_t* d_count = (int32_t*)q; q += sz_i;
+  int32_t* d_size = (int32_t*)q;
+  hipStream_t s = h->stream;
+  HIP_TRY(h, hipMemcpyAsync(d_pos, pos, sizeof(double) * (size_t)N * ndim, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(d_fo, frame_offset, sizeof(int32_t) * (size_t)(n_frames + 1), hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemsetAsync(d_count, 0, sizeof(int32_t) * (size_t)N, s));
+  const double s2 = ndim == 3 ? separation[2] : 1.;
+  if (ndim == 2)
+    hipLaunchKernelGGL(find_clusters_kernel<2>, dim3((unsigned)n_frames), dim3(FC_THREADS), 0, s, d_pos, d_fo,
+                       separation[0], separation[1], s2, d_spos, d_label, d_count, d_size);
+  else
+    hipLaunchKernelGGL(find_clusters_kernel<3>, dim3((unsigned)n_frames), dim3(FC_THREADS), 0, s, d_pos, d_fo,
+                       separation[0], separation[1], s2, d_spos, d_label, d_count, d_size);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(label_out, d_label, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(size_out, d_size, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  return CTR_OK;
+}
 
 int ctr_synchronize(ctr_handle* h, void* hip_stream) {
   if (!h) return CTR_ERR_INVALID;

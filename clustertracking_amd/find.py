@@ -87,10 +87,33 @@ def label_frames(pos, frames, separation):
     return order, ids, sizes
 
 
-def find_clusters(f, separation, pos_columns=None, t_column='frame'):
+def label_frames_device(pos, frames, separation, device=0):
+    """Same contract as :func:`label_frames`, computed by the HIP engine
+    (``ctr_find_clusters``).  The partition equals the reference's; the ids are
+    canonical (smallest frame-sorted row index of the cluster) instead of the
+    reference's set-order-dependent ones."""
+    from . import _lib
+    pos = np.asarray(pos, dtype=np.float64)
+    frames = np.asarray(frames)
+    order = np.argsort(frames, kind='stable')
+    fs = frames[order]
+    n = len(order)
+    if n == 0:
+        return order, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+    starts = np.flatnonzero(np.r_[True, fs[1:] != fs[:-1]])
+    offsets = np.r_[starts, n].astype(np.int32)
+    labels, sizes = _lib.default_engine(device).find_clusters(pos[order], offsets, separation)
+    return order, labels.astype(np.int64), sizes.astype(np.int64)
+
+
+def find_clusters(f, separation, pos_columns=None, t_column='frame', labels='reference',
+                  device=0):
     """Copy of ``f`` (rows grouped by frame) with ``cluster`` and
     ``cluster_size`` columns (reference find.py:132-163).  One pass over NumPy
-    arrays instead of a DataFrame copy per frame; same rows, order and labels."""
+    arrays instead of a DataFrame copy per frame; same rows, order and labels.
+
+    ``labels='device'`` computes the same partition on the MI355X
+    (``ctr_find_clusters``) with canonical ids (smallest row of the cluster)."""
     if pos_columns is None:
         pos_columns = guess_pos_columns(f)
     separation = np.array(validate_tuple(separation, len(pos_columns)),
@@ -99,7 +122,12 @@ def find_clusters(f, separation, pos_columns=None, t_column='frame'):
         frames = f[t_column].values
     else:
         frames = np.zeros(len(f), dtype=np.int64)
-    order, ids, sizes = label_frames(f[pos_columns].values, frames, separation)
+    if labels == 'reference':
+        order, ids, sizes = label_frames(f[pos_columns].values, frames, separation)
+    elif labels == 'device':
+        order, ids, sizes = label_frames_device(f[pos_columns].values, frames, separation, device)
+    else:
+        raise ValueError("labels must be 'reference' or 'device'")
     result = f.iloc[order].copy()
     if t_column not in f:
         result[t_column] = 0   # the reference's output carries the temporary column (find.py:149-157)

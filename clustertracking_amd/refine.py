@@ -66,7 +66,7 @@ def prepare_batch(f, reader, diameter, separation=None, fit_function='gauss',
                   param_mode=None, param_val=None, constraints=None, bounds=None,
                   pos_columns=None, t_column='frame', max_iter=10, max_shift=1,
                   max_rms_dev=1., residual_factor=100000., solver_maxiter=100,
-                  xtol=0., ftol=0.):
+                  xtol=0., ftol=0., cluster_labels='reference', device=0):
     """Host-side set-up of one refine call (reference refine.py:242-341)."""
     if pos_columns is None:
         pos_columns = guess_pos_columns(f)
@@ -93,7 +93,8 @@ def prepare_batch(f, reader, diameter, separation=None, fit_function='gauss',
                                   "implemented (reference refine.py:339-340)")
     cons = engine_constraint(constraints, ndim)
 
-    f = find_clusters(f, separation, pos_columns, t_column)  # makes a copy
+    f = find_clusters(f, separation, pos_columns, t_column, labels=cluster_labels,
+                      device=device)  # makes a copy
     if param_val is not None:
         for col in param_val:
             f[col] = param_val[col]
@@ -200,7 +201,9 @@ def refine_leastsq(f, reader, diameter, separation=None, fit_function='gauss',
       convergence, not SciPy SLSQP at ``tol=1e-6``: ``method`` and ``tol`` in
       ``kwargs`` are accepted and ignored; ``options['maxiter']`` (default 100)
       caps the solver iterations per re-window round.  Engine-specific keys:
-      ``xtol``, ``ftol``, ``device``.
+      ``xtol``, ``ftol``, ``device``, ``cluster_labels`` ('reference': ids equal to
+      the reference's, labelled on the host; 'device': same partition labelled on
+      the GPU, canonical ids).
     * ``fit_function`` other than ``'gauss'``, ``param_mode`` value
       ``'global'``, ``noise_size`` and ``compute_error`` raise
       ``NotImplementedError`` (there is no CPU fallback to hand them to).
@@ -215,6 +218,7 @@ def refine_leastsq(f, reader, diameter, separation=None, fit_function='gauss',
     xtol = kwargs.pop('xtol', 0.)
     ftol = kwargs.pop('ftol', 0.)
     device = kwargs.pop('device', 0)
+    cluster_labels = kwargs.pop('cluster_labels', 'reference')
     run_batch = kwargs.pop('_run_batch', None)  # test hook (oracle on CPU)
     if kwargs:
         raise TypeError("unexpected keyword arguments: %s" % sorted(kwargs))
@@ -230,7 +234,7 @@ def refine_leastsq(f, reader, diameter, separation=None, fit_function='gauss',
                          pos_columns, t_column, max_iter, max_shift,
                          max_rms_dev, residual_factor,
                          solver_maxiter=int(options.get('maxiter', 100)),
-                         xtol=xtol, ftol=ftol)
+                         xtol=xtol, ftol=ftol, cluster_labels=cluster_labels, device=device)
     if prep.batch.n_clusters:
         if run_batch is None:
             _run_on_engine(prep.problem, prep.batch, device)

@@ -159,6 +159,16 @@ int ctr_frame_max_device(ctr_handle* h, const void* frames, int32_t frame_dtype,
                          int64_t n_frames, int64_t frame_elems, double* out_max,
                          void* hip_stream);
 
+/* Cluster labelling on the device (replaces reference find.py:72-93, the step right
+ * before the hot path): rows [frame_offset[f], frame_offset[f+1]) of `pos` are the
+ * features of frame f (table sorted by frame); two features of a frame closer than
+ * `separation` (per-axis scaled distance <= 1, as cKDTree(pos/separation).query_pairs(1))
+ * share a cluster.  label_out[i] = smallest row index of i's cluster (canonical: the
+ * reference's own ids depend on Python set order; the partition is the same),
+ * size_out[i] = number of features in it.  Host pointers, synchronous. */
+int ctr_find_clusters(ctr_handle* h, int32_t ndim, const double* pos, const int32_t* frame_offset,
+                      int64_t n_frames, const double* separation, int32_t* label_out, int32_t* size_out);
+
 /* Block until the work queued by the *_device calls on `hip_stream` is done. */
 int ctr_synchronize(ctr_handle* h, void* hip_stream);
 

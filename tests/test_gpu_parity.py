@@ -252,3 +252,52 @@ def test_empty_batch_and_bad_descriptor(engine):
     b.frame_index[0] = 3
     with pytest.raises(ValueError):
         engine.refine_batch(prob, b)
+
+
+# ---- cluster labelling on the device (find.py:72-93) ----------------------
+
+def same_partition(a, b):
+    """two labelings induce the same partition"""
+    a, b = np.asarray(a), np.asarray(b)
+    fa = {}
+    fb = {}
+    for x, y in zip(a, b):
+        if fa.setdefault(x, y) != y or fb.setdefault(y, x) != x:
+            return False
+    return True
+
+
+def test_find_clusters_device_partition_equals_reference_rule(engine):
+    from clustertracking_amd import find
+    rng = np.random.RandomState(11)
+    cases = []
+    frames, f0, truth, opts = workloads.cfg2(64, 0)
+    cases.append((f0[['y', 'x']].values, f0['frame'].values, (13., 13.)))
+    frames3, f3, t3, o3 = workloads.cfg3(3, 0, n_features=300)
+    cases.append((f3[['z', 'y', 'x']].values, f3['frame'].values, (9., 17., 17.)))
+    # chains: every feature only touches its neighbour (worst case for label propagation)
+    chain = np.column_stack([np.full(400, 10.), np.arange(400) * 0.99])
+    cases.append((rng.permutation(chain), np.zeros(400, int), (1., 1.)))
+    pos = rng.uniform(0, 60, (3000, 2))
+    cases.append((pos, rng.randint(0, 7, 3000), (2.5, 1.5)))
+    for pos, fr, sep in cases:
+        sep = np.array(sep)
+        o1, ids, sizes = find.label_frames(pos, fr, sep)
+        o2, ids_d, sizes_d = find.label_frames_device(pos, fr, sep)
+        assert_equal(o1, o2)
+        assert same_partition(ids, ids_d)
+        assert_equal(sizes, sizes_d)
+        # canonical id = smallest row of the cluster, so ids grow with the frame
+        assert (ids_d <= np.arange(len(ids_d))).all()
+        assert (ids_d[ids_d] == ids_d).all()
+
+
+def test_refine_with_device_labels_matches_reference_labels(engine):
+    frames, f0, truth, opts = workloads.cfg2(6, 3)
+    r_ref = cta.refine_leastsq(f0.copy(), cta.ArrayReader(frames), 13)
+    r_dev = cta.refine_leastsq(f0.copy(), cta.ArrayReader(frames), 13, cluster_labels='device')
+    assert_equal(np.asarray(r_ref.index), np.asarray(r_dev.index))
+    assert same_partition(r_ref['cluster'].values, r_dev['cluster'].values)
+    assert_equal(r_ref['cluster_size'].values, r_dev['cluster_size'].values)
+    for col in ('y', 'x', 'signal', 'background', 'cost'):
+        assert_equal(r_ref[col].values, r_dev[col].values)
