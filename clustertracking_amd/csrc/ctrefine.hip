@@ -181,13 +181,6 @@ __device__ __forceinline__ void wsync() {
 // right-hand side rides along as one more row, so the forward substitution is
 // free.  The back substitution broadcasts each solved component once.  No LDS
 // round trips, no dynamic register indexing.  Returns false if not positive definite.
-__device__ __forceinline__ double readlane_f64(double x, int srclane) {
-  const long long b = __double_as_longlong(x);
-  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), srclane);
-  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
 // 1/sqrt(x) to double precision: hardware estimate + two Newton steps (the
 // correctly rounded sqrt and division cost ~60 dependent instructions per pivot)
 __device__ __forceinline__ double fast_rsqrt(double x) {
@@ -195,6 +188,13 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
   r = r * fma(-0.5 * x * r, r, 1.5);
   r = r * fma(-0.5 * x * r, r, 1.5);
   return r;
+}
+
+__device__ __forceinline__ double readlane_f64(double x, int srclane) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), srclane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 template <int NR>
@@ -281,53 +281,50 @@ struct SmemB {
 
 enum { BP_EVAL_INIT = 1, BP_EVAL_TRIAL = 2, BP_STEP_ONLY = 3, BP_FINISH = 4 };
 
-// in-place Cholesky of a packed lower-triangular matrix in LDS by ONE wave
-__device__ bool chol_factor_w(double* Hp, int nf, int lane) {
+// in-place Cholesky of a packed lower-triangular matrix in LDS by ONE wave.
+// Right-looking: per column one reciprocal square root, then the trailing
+// update spread over the lanes as an 8 x 8 grid of (row, column) entries, so a
+// lane does ~(nf - j)^2 / 128 multiply-subtracts per column instead of nf - j.
+// dinv[j] = 1 / L[j][j] is kept for the substitutions.
+__device__ bool chol_factor_w(double* Hp, double* dinv, int nf, int lane) {
+  const int ty = lane >> 3, tx = lane & 7;
   for (int j = 0; j < nf; ++j) {
-    for (int i = lane; i < nf; i += WAVE) {
-      if (i < j) continue;
-      double s = Hp[tri(i) + j];
-      const double* ri = Hp + tri(i);
-      const double* rj = Hp + tri(j);
-      for (int kk = 0; kk < j; ++kk) s -= ri[kk] * rj[kk];
-      Hp[tri(i) + j] = s;
-    }
-    wsync();
     const double d = Hp[tri(j) + j];
     if (!(d > 0.) || !isfinite(d)) return false;
-    const double sd = sqrt(d);
+    const double inv = fast_rsqrt(d);
     wsync();
-    for (int i = lane; i < nf; i += WAVE) {
-      if (i > j) Hp[tri(i) + j] /= sd;
-      else if (i == j) Hp[tri(j) + j] = sd;
+    for (int i = j + 1 + lane; i < nf; i += WAVE) Hp[tri(i) + j] *= inv;
+    if (lane == 0) { Hp[tri(j) + j] = d * inv; dinv[j] = inv; }
+    wsync();
+    for (int i = j + 1 + ty; i < nf; i += 8) {
+      const double lij = Hp[tri(i) + j];
+      double* ri = Hp + tri(i);
+      for (int kk = j + 1 + tx; kk <= i; kk += 8) ri[kk] -= lij * Hp[tri(kk) + j];
     }
     wsync();
   }
   return true;
 }
 
-__device__ void chol_solve_w(const double* Lp, int nf, double* x, int nrhs, int ldx, int lane) {
+// solve L L^T x = b in place for nrhs right-hand sides x[r*ldx + i]
+__device__ void chol_solve_w(const double* Lp, const double* dinv, int nf, double* x, int nrhs,
+                             int ldx, int lane) {
   for (int j = 0; j < nf; ++j) {
-    const double ljj = Lp[tri(j) + j];
+    const double dj = dinv[j];
     for (int r = 0; r < nrhs; ++r) {
-      const double yj = x[r * ldx + j] / ljj;
-      for (int i = lane; i < nf; i += WAVE)
-        if (i > j) x[r * ldx + i] -= Lp[tri(i) + j] * yj;
+      const double yj = x[r * ldx + j] * dj;
+      for (int i = j + 1 + lane; i < nf; i += WAVE) x[r * ldx + i] -= Lp[tri(i) + j] * yj;
+      if (lane == 0) x[r * ldx + j] = yj;
     }
-    wsync();
-    if (lane == 0)
-      for (int r = 0; r < nrhs; ++r) x[r * ldx + j] /= ljj;
     wsync();
   }
   for (int j = nf - 1; j >= 0; --j) {
-    const double ljj = Lp[tri(j) + j];
+    const double dj = dinv[j];
     for (int r = 0; r < nrhs; ++r) {
-      const double xj = x[r * ldx + j] / ljj;
+      const double xj = x[r * ldx + j] * dj;
       for (int i = lane; i < j; i += WAVE) x[r * ldx + i] -= Lp[tri(j) + i] * xj;
+      if (lane == 0) x[r * ldx + j] = xj;
     }
-    wsync();
-    if (lane == 0)
-      for (int r = 0; r < nrhs; ++r) x[r * ldx + j] /= ljj;
     wsync();
   }
 }
@@ -833,16 +830,16 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             Hp[e] = h;
           }
           wsync();
-          ok_step = chol_factor_w(Hp, nf, lane);
+          ok_step = chol_factor_w(Hp, dl, nf, lane);  // dl doubles as 1/diag until the step is built
           if (ok_step) {
             for (int a = lane; a < nf; a += WAVE) {
               w[a] = Mp[tri(nv) + fr[a]];
               for (int r = 0; r < m; ++r) Y[r * LDC + a] = Cj[r * LDC + fr[a]];
             }
             wsync();
-            chol_solve_w(Hp, nf, w, 1, 0, lane);
+            chol_solve_w(Hp, dl, nf, w, 1, 0, lane);
             if (m) {
-              chol_solve_w(Hp, nf, Y, m, LDC, lane);
+              chol_solve_w(Hp, dl, nf, Y, m, LDC, lane);
               // (C H^-1 C^T) mult = c - C H^-1 g   (range-space form of the KKT step)
               if (lane < m * m) {
                 const int r = lane / m, s = lane % m;
