@@ -91,9 +91,10 @@ def load():
                                              C.c_int64, C.c_int64, C.c_void_p,
                                              C.c_void_p]
         lib.ctr_frame_max_device.restype = C.c_int
-        lib.ctr_find_clusters.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
-                                          C.c_void_p, C.c_void_p, C.c_void_p]
-        lib.ctr_find_clusters.restype = C.c_int
+        if hasattr(lib, 'ctr_find_clusters'):   # absent only in older diagnostic builds
+            lib.ctr_find_clusters.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                              C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+            lib.ctr_find_clusters.restype = C.c_int
         lib.ctr_synchronize.argtypes = [C.c_void_p, C.c_void_p]
         lib.ctr_synchronize.restype = C.c_int
         lib.ctr_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_double), P(C.c_double)]

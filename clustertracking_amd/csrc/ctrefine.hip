@@ -1,21 +1,22 @@
 // ctrefine.hip -- MI355X (gfx950) cluster-refinement engine behind include/ctrefine.h.
 //
-// One wavefront (64 lanes) fits one cluster, start to finish, without leaving
-// the CU: window (reference masks.py:30-68), elliptical masks (refine.py:43-51),
-// sum-of-Gaussians residual and Jacobian rows (fitfunc.py:14-118,436-487), the
-// normal equations, the bounded / equality-constrained Levenberg-Marquardt step,
-// the re-window rounds and the failure rules (refine.py:343-430).
+// A cluster is fitted start to finish on the chip: window (reference masks.py:30-68),
+// elliptical masks (refine.py:43-51), sum-of-Gaussians residual and Jacobian rows
+// (fitfunc.py:14-118,436-487), normal equations, bounded / equality-constrained
+// Levenberg-Marquardt step, re-window rounds and failure rules (refine.py:343-430).
 //
-// Data flow per solver iteration, per 64-pixel tile of the window:
-//   lane = pixel:  residual + Jacobian row  ->  LDS row tile R[64][16*NT+1] (f64)
-//   wave:          M += R^T R  with v_mfma_f64_16x16x4_f64, NT*(NT+1)/2 tiles of
-//                  the augmented matrix [J r]^T [J r] kept in registers
-// so J^T J, J^T r need no cross-lane reduction; M goes to LDS only when a step
-// is accepted.  Linear algebra (active-set reduction, Cholesky, range-space step
-// for the equality constraints) runs cooperatively on LDS.
-//
-// NT (16-column tiles of [J r]) is a template parameter; clusters are binned by
-// NT on the host (ctr_plan_create).  No CUDA paths, no fallback.
+// Kernels:
+//   frame_max_kernel      per-frame maximum (refine.py:354); HBM streaming
+//   refine_small_kernel   singles / pairs with the default parameter modes: 16 or 64 lanes per
+//                         cluster, [J r]^T [J r] accumulated in registers, DPP row all-reduce,
+//                         register-resident solve, clusters pulled from a work counter
+//   refine_block_kernel   everything else: W wavefronts per cluster, Jacobian rows staged in LDS
+//                         and contracted with v_mfma_f64_16x16x4_f64, partial accumulators meet
+//                         in LDS, register column-Cholesky (<= 31 variables) or cooperative LDS
+//                         Cholesky + range-space KKT step (constraints)
+//   find_clusters_kernel  cluster labelling of a frame (find.py:72-93)
+// Clusters are binned by problem size on the host (ctr_plan_create); the bins run
+// concurrently on forked streams.  gfx950 only; no CUDA paths, no CPU fallback.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -226,10 +227,8 @@ __device__ __forceinline__ bool column_solve(const double* Mp, int nv, double mu
       if (c == j) { mydinv = dinv; yown = yj; }
 #pragma unroll
       for (int i = j + 1; i < NR; ++i) {
-        if (i < nv) {  // uniform: the rows beyond the variables stay identity
-          const double lij = readlane_f64(col[i], j) * dinv;
-          col[i] -= lij * lkj;
-        }
+        const double lij = readlane_f64(col[i], j) * dinv;
+        col[i] -= lij * lkj;
       }
       y -= yj * lkj;
     }
