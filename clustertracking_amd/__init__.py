@@ -10,9 +10,10 @@ from .refine import refine_leastsq, prepare_batch, write_back
 from .find import find_clusters
 from .fitfunc import FitFunctions
 from .utils import ArrayReader, RefineException
+from .link import link
 from . import constraints, artificial
 
-__all__ = ['refine_leastsq', 'find_clusters', 'FitFunctions', 'constraints',
+__all__ = ['refine_leastsq', 'find_clusters', 'link', 'FitFunctions', 'constraints',
            'artificial', 'ArrayReader', 'RefineException', 'prepare_batch',
            'write_back']
 

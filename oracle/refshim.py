@@ -11,7 +11,8 @@ arithmetic is altered:
 * ``trackpy.utils.validate_tuple``: scalar -> (v,)*ndim, len-ndim iterable ->
   tuple, else ValueError (behaviour inferred from refine.py:30,285 and
   masks.py:11,53 call sites).
-* ``np.bool / np.int / np.float`` aliases (used at refine.py:49, masks.py:54).
+* ``np.bool / np.int / np.float / np.Inf`` aliases (used at refine.py:49,
+  masks.py:54, find_link.py:527).
 * ``masks.slice_image`` indexes with a *list* of slices (masks.py:68), an
   IndexError on NumPy >= 1.23; rebound to index with ``tuple(slices)``.
 
@@ -56,8 +57,8 @@ def load():
     if not available():
         raise ImportError("reference not present at %s" % REFERENCE_ROOT)
 
-    for alias, typ in (("bool", bool), ("int", int), ("float", float)):
-        if not hasattr(np, alias):
+    for alias, typ in (("bool", bool), ("int", int), ("float", float), ("Inf", np.inf)):
+        if not hasattr(np, alias):   # removed in NumPy 2 (np.Inf: find_link.py:527)
             setattr(np, alias, typ)
 
     tp = types.ModuleType("trackpy")
