@@ -10,10 +10,11 @@ from .refine import refine_leastsq, prepare_batch, write_back
 from .find import find_clusters
 from .fitfunc import FitFunctions
 from .utils import ArrayReader, RefineException
-from .link import link
-from . import constraints, artificial
+from . import constraints, artificial, link
 
-__all__ = ['refine_leastsq', 'find_clusters', 'link', 'FitFunctions', 'constraints',
+link_df = link.link
+
+__all__ = ['refine_leastsq', 'find_clusters', 'link', 'link_df', 'FitFunctions', 'constraints',
            'artificial', 'ArrayReader', 'RefineException', 'prepare_batch',
            'write_back']
 
