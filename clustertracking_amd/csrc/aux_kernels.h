@@ -1,0 +1,165 @@
+// aux_kernels.h -- mark_kernel, find_clusters_kernel, frame_max_kernel
+// Part of the MI355X cluster-refinement engine; included by ctrefine.hip inside its
+// anonymous namespace (device code only, gfx950).
+#ifndef CTREFINE_AUX_KERNELS_H
+#define CTREFINE_AUX_KERNELS_H
+
+// clusters the engine cannot take (too many variables / features)
+__global__ void mark_kernel(const KArgs k, int code) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k.n_bin) return;
+  const int cl = k.order[t];
+  const int np = k.prob.n_params;
+  for (int e = k.feat_offset[cl] * np; e < k.feat_offset[cl + 1] * np; ++e) k.params_out[e] = k.params[e];
+  k.status[cl] = code;
+  k.cost[cl] = NAN;
+  k.n_rounds[cl] = 0;
+  k.n_iter[cl] = 0;
+}
+
+
+// ---- cluster labelling (reference find.py:72-93): which features are fitted together ----
+// Features of one frame closer than `separation` (per-axis scaled Euclidean distance <= 1,
+// the criterion of cKDTree(pos / separation).query_pairs(1)) share a cluster.  One workgroup
+// per frame; label propagation to the smallest row index of the cluster until nothing
+// changes (bounded by the number of features of the frame).  The label is canonical (the
+// reference's ids depend on Python set order); the PARTITION is the reference's.
+constexpr int FC_THREADS = 256;
+
+template <int ND>
+__global__ void __launch_bounds__(FC_THREADS) find_clusters_kernel(const double* __restrict__ pos,
+                                                                   const int32_t* __restrict__ frame_offset,
+                                                                   double s0, double s1, double s2,
+                                                                   double* __restrict__ spos, int32_t* label,
+                                                                   int32_t* __restrict__ count,
+                                                                   int32_t* __restrict__ size_out) {
+  const int f = blockIdx.x;
+  const int r0 = frame_offset[f], r1 = frame_offset[f + 1];
+  const double sep[3] = {s0, s1, s2};
+  for (int i = r0 + threadIdx.x; i < r1; i += FC_THREADS) {
+#pragma unroll
+    for (int a = 0; a < ND; ++a) spos[(size_t)i * ND + a] = pos[(size_t)i * ND + a] / sep[a];
+    label[i] = i;
+  }
+  __syncthreads();
+  for (int sweep = 0; sweep <= r1 - r0; ++sweep) {
+    bool changed = false;
+    for (int i = r0 + threadIdx.x; i < r1; i += FC_THREADS) {
+      double p[ND];
+#pragma unroll
+      for (int a = 0; a < ND; ++a) p[a] = spos[(size_t)i * ND + a];
+      const int mine = __hip_atomic_load(&label[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      int m = mine;
+      for (int j = r0; j < r1; ++j) {
+        double d2 = 0.;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+          const double d = p[a] - spos[(size_t)j * ND + a];
+          d2 += d * d;
+        }
+        if (d2 <= 1.) {
+          const int lj = __hip_atomic_load(&label[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          m = lj < m ? lj : m;
+        }
+      }
+      if (m < mine) {
+        __hip_atomic_store(&label[i], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        changed = true;
+      }
+    }
+    if (!__syncthreads_or(changed ? 1 : 0)) break;
+  }
+  // labels of this frame are final: root = smallest row index; count members, then sizes
+  for (int i = r0 + threadIdx.x; i < r1; i += FC_THREADS) atomicAdd(&count[label[i]], 1);
+  __syncthreads();
+  for (int i = r0 + threadIdx.x; i < r1; i += FC_THREADS)
+    size_out[i] = __hip_atomic_load(&count[label[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- per-frame maximum (the norm of refine.py:354) --------------------------------
+// Streams the frame block once: 16 B per lane per load, one ordered-u64 atomicMax
+// per workgroup.  HBM-bound.
+
+__device__ __forceinline__ unsigned long long enc_f64(double x) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dec_f64(unsigned long long e) {
+  unsigned long long b = (e >> 63) ? (e & 0x7fffffffffffffffull) : ~e;
+  return __longlong_as_double((long long)b);
+}
+
+template <typename T>
+__device__ __forceinline__ double chunk_max(const T* p, size_t n, int tid, int nthreads) {
+  constexpr int V = 16 / sizeof(T);
+  double m = -INFINITY;
+  const uintptr_t addr = (uintptr_t)p;
+  size_t head = (16 - (addr & 15)) & 15;
+  head /= sizeof(T);
+  if (head > n) head = n;
+  for (size_t i = tid; i < head; i += nthreads) {
+    const double x = (double)p[i];
+    m = (x > m || x != x) ? x : m;
+  }
+  const size_t nvec = (n - head) / V;
+  const uint4* pv = (const uint4*)(p + head);
+  for (size_t i = tid; i < nvec; i += nthreads) {
+    uint4 raw = pv[i];
+    T vals[V];
+    __builtin_memcpy(vals, &raw, 16);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const double x = (double)vals[j];
+      m = (x > m || x != x) ? x : m;
+    }
+  }
+  for (size_t i = head + nvec * V + tid; i < n; i += nthreads) {
+    const double x = (double)p[i];
+    m = (x > m || x != x) ? x : m;
+  }
+  return m;
+}
+
+constexpr int FM_THREADS = 256;
+constexpr size_t FM_CHUNK_BYTES = 64 * 1024;
+
+__global__ void __launch_bounds__(FM_THREADS) frame_max_kernel(const void* frames, int dtype,
+                                                               size_t frame_elems, int chunks_per_frame,
+                                                               size_t chunk_elems,
+                                                               unsigned long long* enc) {
+  const int frame = blockIdx.x / chunks_per_frame, chunk = blockIdx.x % chunks_per_frame;
+  const size_t begin = (size_t)chunk * chunk_elems;
+  size_t n = frame_elems - begin;
+  if (n > chunk_elems) n = chunk_elems;
+  const size_t e0 = (size_t)frame * frame_elems + begin;
+  double m;
+  switch (dtype) {
+    case CTR_DTYPE_U8: m = chunk_max((const uint8_t*)frames + e0, n, threadIdx.x, FM_THREADS); break;
+    case CTR_DTYPE_U16: m = chunk_max((const uint16_t*)frames + e0, n, threadIdx.x, FM_THREADS); break;
+    case CTR_DTYPE_I16: m = chunk_max((const int16_t*)frames + e0, n, threadIdx.x, FM_THREADS); break;
+    case CTR_DTYPE_I32: m = chunk_max((const int32_t*)frames + e0, n, threadIdx.x, FM_THREADS); break;
+    case CTR_DTYPE_F32: m = chunk_max((const float*)frames + e0, n, threadIdx.x, FM_THREADS); break;
+    default: m = chunk_max((const double*)frames + e0, n, threadIdx.x, FM_THREADS); break;
+  }
+  unsigned long long e = enc_f64(m);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long other = __shfl_xor(e, o);
+    e = other > e ? other : e;
+  }
+  __shared__ unsigned long long part[FM_THREADS / WAVE];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = e;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int wv = 1; wv < FM_THREADS / WAVE; ++wv) e = part[wv] > e ? part[wv] : e;
+    atomicMax(enc + frame, e);
+  }
+}
+
+__global__ void frame_max_decode_kernel(const unsigned long long* enc, double* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = dec_f64(enc[i]);
+}
+
+
+#endif  // CTREFINE_AUX_KERNELS_H

@@ -1,0 +1,857 @@
+// block_kernel.h -- refine_block_kernel: W wavefronts per cluster, LDS row tiles + f64 MFMA
+// Part of the MI355X cluster-refinement engine; included by ctrefine.hip inside its
+// anonymous namespace (device code only, gfx950).
+#ifndef CTREFINE_BLOCK_KERNEL_H
+#define CTREFINE_BLOCK_KERNEL_H
+
+// ---- generic clusters: one workgroup of W wavefronts per cluster ------------------------
+//
+// Any number of features / any parameter modes / constraints.  The W waves split
+// the 64-pixel tiles of the window among themselves; each builds Jacobian rows in
+// its own LDS row tile and contracts them with v_mfma_f64_16x16x4_f64 into
+// register accumulators of the augmented matrix [J r]^T [J r]; the partial
+// accumulators meet in LDS, wave 0 runs the bounded / constrained LM step on the
+// sum (cooperative Cholesky on LDS) and publishes the next trial vector.  Two
+// workgroup barriers per solver iteration.  W = 4 (NT <= 3), 2 (NT <= 6), 1.
+
+__device__ __forceinline__ void wsync() {
+  // LDS ordering inside ONE wavefront (DS operations of a wave execute in order)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+
+// ---- register-resident Cholesky step for small systems (one matrix column per lane) ----
+//
+// Lane c < NR holds column c of the damped normal matrix with the active set
+// folded in (fixed variables and unused rows are identity rows).  Right-looking
+// Cholesky: at step j the pivot column is broadcast row by row with v_readlane,
+// every later column updates itself from its own (symmetric) entry col[j]; the
+// right-hand side rides along as one more row, so the forward substitution is
+// free.  The back substitution broadcasts each solved component once.  No LDS
+// round trips, no dynamic register indexing.  Returns false if not positive definite.
+// 1/sqrt(x) to double precision: hardware estimate + two Newton steps (the
+// correctly rounded sqrt and division cost ~60 dependent instructions per pivot)
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  return r;
+}
+
+__device__ __forceinline__ double readlane_f64(double x, int srclane) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), srclane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <int NR>
+__device__ __forceinline__ bool column_solve(const double* Mp, int nv, double mu, bool is_free,
+                                             int lane, double& x_own) {
+  const int c = lane;
+  const bool colv = c < nv && is_free;
+  const unsigned long long fmask = __ballot(colv);
+  double col[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const bool rowv = ((fmask >> i) & 1ull) != 0ull;
+    double x = 0.;
+    if (rowv && colv) x = Msym(Mp, i, c);
+    if (i == c) x = colv ? x + mu * (x > 1e-300 ? x : 1.) : 1.;
+    col[i] = x;
+  }
+  double y = colv ? Mp[tri(nv) + c] : 0.;
+  double mydinv = 1., yown = 0.;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    if (j < nv) {  // rows beyond the variables are identity: nothing to eliminate (uniform branch)
+      const double dj = readlane_f64(col[j], j);
+      if (!(dj > 0.) || !isfinite(dj)) ok = false;
+      const double dinv = fast_rsqrt(dj);
+      const double lkj = c > j ? col[j] * dinv : 0.;  // L[c][j] for the columns still open
+      const double yj = readlane_f64(y, j) * dinv;
+      if (c == j) { mydinv = dinv; yown = yj; }
+#pragma unroll
+      for (int i = j + 1; i < NR; ++i) {
+        const double lij = readlane_f64(col[i], j) * dinv;
+        col[i] -= lij * lkj;
+      }
+      y -= yj * lkj;
+    }
+  }
+  double s = 0.;
+  x_own = 0.;
+#pragma unroll
+  for (int j = NR - 1; j >= 0; --j) {
+    if (j < nv) {
+      const double xj = readlane_f64((yown - s) * mydinv, j);
+      if (c == j) x_own = xj;
+      s += (c < j ? col[j] * mydinv : 0.) * xj;
+    }
+  }
+  return ok;
+}
+
+template <int NT, int W>
+struct SmemB {
+  static constexpr int NVP = 16 * NT;
+  static constexpr int RS = NVP + 1;
+  static constexpr int NTILE = NT * (NT + 1) / 2;
+  static constexpr int NF = NVP < MAXF ? NVP : MAXF;
+  static constexpr int NVC = NVP < 32 ? NVP : 32;
+  static constexpr int ROWS = WAVE * RS;               // one wave's row tile
+  static constexpr int o_rows = 0;                      // W row tiles; tile 0 doubles as packed H
+  static constexpr int o_M = o_rows + W * ROWS;
+  static constexpr int o_v = o_M + NVP * (NVP + 1) / 2;
+  static constexpr int o_vt = o_v + NVP;
+  static constexpr int o_v0 = o_vt + NVP;
+  static constexpr int o_lo = o_v0 + NVP;
+  static constexpr int o_hi = o_lo + NVP;
+  static constexpr int o_dl = o_hi + NVP;
+  static constexpr int o_w = o_dl + NVP;
+  static constexpr int o_cur = o_w + NVP;
+  static constexpr int o_mco = o_cur + NF * CTR_MAX_PARAMS;
+  static constexpr int o_fpar = o_mco + NF * 3;
+  static constexpr int o_Cj = o_fpar + NF * FP;
+  static constexpr int o_Cjt = o_Cj + MAXC * NVC;
+  static constexpr int o_Y = o_Cjt + MAXC * NVC;
+  static constexpr int o_small = o_Y + MAXC * NVC;      // cv[6] cvt[6] mult[6] . Sc[36] flag
+  static constexpr int o_fr = o_small + 64;
+  static constexpr int o_part = o_fr + NVP / 2 + 2;     // per wave: S, P
+  static constexpr int o_ctl = o_part + 2 * W;          // ints: phase, origin[3], wshape[3]
+  static constexpr int total = o_ctl + 8;
+  static constexpr size_t bytes = (size_t)total * sizeof(double);
+  static_assert(W == 1 || NTILE * 256 <= ROWS, "partial accumulators must fit a row tile");
+};
+
+enum { BP_EVAL_INIT = 1, BP_EVAL_TRIAL = 2, BP_STEP_ONLY = 3, BP_FINISH = 4 };
+
+// in-place Cholesky of a packed lower-triangular matrix in LDS by ONE wave.
+// Right-looking: per column one reciprocal square root, then the trailing
+// update spread over the lanes as an 8 x 8 grid of (row, column) entries, so a
+// lane does ~(nf - j)^2 / 128 multiply-subtracts per column instead of nf - j.
+// dinv[j] = 1 / L[j][j] is kept for the substitutions.
+__device__ bool chol_factor_w(double* Hp, double* dinv, int nf, int lane) {
+  const int ty = lane >> 3, tx = lane & 7;
+  for (int j = 0; j < nf; ++j) {
+    const double d = Hp[tri(j) + j];
+    if (!(d > 0.) || !isfinite(d)) return false;
+    const double inv = fast_rsqrt(d);
+    wsync();
+    for (int i = j + 1 + lane; i < nf; i += WAVE) Hp[tri(i) + j] *= inv;
+    if (lane == 0) { Hp[tri(j) + j] = d * inv; dinv[j] = inv; }
+    wsync();
+    for (int i = j + 1 + ty; i < nf; i += 8) {
+      const double lij = Hp[tri(i) + j];
+      double* ri = Hp + tri(i);
+      for (int kk = j + 1 + tx; kk <= i; kk += 8) ri[kk] -= lij * Hp[tri(kk) + j];
+    }
+    wsync();
+  }
+  return true;
+}
+
+// solve L L^T x = b in place for nrhs right-hand sides x[r*ldx + i]
+__device__ void chol_solve_w(const double* Lp, const double* dinv, int nf, double* x, int nrhs,
+                             int ldx, int lane) {
+  for (int j = 0; j < nf; ++j) {
+    const double dj = dinv[j];
+    for (int r = 0; r < nrhs; ++r) {
+      const double yj = x[r * ldx + j] * dj;
+      for (int i = j + 1 + lane; i < nf; i += WAVE) x[r * ldx + i] -= Lp[tri(i) + j] * yj;
+      if (lane == 0) x[r * ldx + j] = yj;
+    }
+    wsync();
+  }
+  for (int j = nf - 1; j >= 0; --j) {
+    const double dj = dinv[j];
+    for (int r = 0; r < nrhs; ++r) {
+      const double xj = x[r * ldx + j] * dj;
+      for (int i = lane; i < j; i += WAVE) x[r * ldx + i] -= Lp[tri(j) + i] * xj;
+      if (lane == 0) x[r * ldx + j] = xj;
+    }
+    wsync();
+  }
+}
+
+#ifdef CTR_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP(slot) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    if (wave == 0 && lane == 0) atomicAdd(&g_stamps[slot], now_ - t_prev_); t_prev_ = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
+template <int ND, bool ISO, int NT, int W>
+__global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
+#ifdef CTR_STAMPS
+  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#endif
+  using SM = SmemB<NT, W>;
+  constexpr int NP = 2 + ND + (ISO ? 1 : ND);
+  constexpr int NSZ = ISO ? 1 : ND;
+  constexpr int LDC = SM::NVC;
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cl = k.order[blockIdx.x];
+  const int f0 = k.feat_offset[cl], n = k.feat_offset[cl + 1] - f0;
+  const double* params = k.params + (size_t)f0 * NP;
+  double* pout = k.params_out + (size_t)f0 * NP;
+
+  double *v = smem + SM::o_v, *vt = smem + SM::o_vt, *v0 = smem + SM::o_v0, *lo = smem + SM::o_lo,
+         *hi = smem + SM::o_hi, *dl = smem + SM::o_dl, *w = smem + SM::o_w, *Mp = smem + SM::o_M,
+         *Hp = smem + SM::o_rows, *cur = smem + SM::o_cur, *mco = smem + SM::o_mco,
+         *fpar = smem + SM::o_fpar, *part = smem + SM::o_part;
+  double *Cj = smem + SM::o_Cj, *Cjt = smem + SM::o_Cjt, *Y = smem + SM::o_Y;
+  double *cv = smem + SM::o_small, *cvt = cv + 6, *mult = cv + 12, *Sc = cv + 24, *flag = cv + 60;
+  int* fr = (int*)(smem + SM::o_fr);
+  int* ctl = (int*)(smem + SM::o_ctl);
+  double* myrows = smem + SM::o_rows + wave * SM::ROWS;
+
+  Layout L;
+  make_layout(k.prob, n, L);
+  const int nv = L.nv;
+  const int m = n_constraints(k.prob, n);
+  const void* frame = (const char*)k.frames + (size_t)k.frame_index[cl] * k.frame_elems * dtype_size(k.frame_dtype);
+  const int maxiter = k.prob.solver_maxiter > 0 ? k.prob.solver_maxiter : 100;
+  const double xtol = k.prob.xtol > 0 ? k.prob.xtol : 1e-9;
+  const double ftol = k.prob.ftol > 0 ? k.prob.ftol : 1e-14;
+  int radius[ND];
+  double inv_r2[ND];
+  long fshape[ND];
+#pragma unroll
+  for (int a = 0; a < ND; ++a) {
+    radius[a] = k.prob.radius[a];
+    inv_r2[a] = 1. / ((double)radius[a] * (double)radius[a]);
+    fshape[a] = k.shape[a];
+  }
+  // parameter kk of feature i at vector vv (vect_to_params, fitfunc.py:266-315)
+  auto par = [&](const double* vv, int i, int kk) -> double {
+    const int b = L.var_of[kk];
+    if (b < 0) return cur[i * CTR_MAX_PARAMS + kk];
+    return vv[b + (L.per_feat[kk] ? i : 0)];
+  };
+  // derived constants of every feature at vv: [0] signal [1..3] centre
+  // [4..6] 1/size^2 [7..9] 2/size^2 [10..12] -2/size^3   (wave 0)
+  bool size_is_var = false;
+#pragma unroll
+  for (int kk = 2 + ND; kk < NP; ++kk) size_is_var = size_is_var || L.var_of[kk] >= 0;
+  auto fill_fpar = [&](const double* vv, bool sizes) {
+    for (int i = lane; i < n; i += WAVE) {
+      double* f = fpar + i * FP;
+      f[0] = par(vv, i, 1);
+#pragma unroll
+      for (int a = 0; a < ND; ++a) {
+        f[1 + a] = par(vv, i, 2 + a);
+        if (sizes) {  // three f64 divisions per axis: only when a size actually changed
+          const double sz = par(vv, i, ISO ? 2 + ND : 2 + ND + a);
+          const double s2 = sz * sz;
+          f[4 + a] = 1. / s2;
+          f[7 + a] = 2. / s2;
+          f[10 + a] = -2. / (s2 * sz);
+        }
+      }
+    }
+  };
+  // masks.py:42-68 on the mask centres; wave-uniform
+  auto window_of = [&](int* origin, int* wshape) -> bool {
+    long wlo[ND], whi[ND];
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+      long ci[ND];
+      bool ok = true;
+#pragma unroll
+      for (int a = 0; a < ND; ++a) {
+        ci[a] = (long)rint(mco[i * 3 + a]);
+        if (!(ci[a] >= -(long)radius[a] && ci[a] < fshape[a] + radius[a])) ok = false;
+      }
+      if (!ok) continue;
+#pragma unroll
+      for (int a = 0; a < ND; ++a) {
+        wlo[a] = (!any || ci[a] < wlo[a]) ? ci[a] : wlo[a];
+        whi[a] = (!any || ci[a] > whi[a]) ? ci[a] : whi[a];
+      }
+      any = true;
+    }
+    if (!any) return false;
+#pragma unroll
+    for (int a = 0; a < ND; ++a) {
+      long l = wlo[a] - radius[a], u = whi[a] + radius[a] + 1;
+      l = l < 0 ? 0 : l;
+      u = u > fshape[a] ? fshape[a] : u;
+      origin[a] = (int)l;
+      wshape[a] = (int)(u - l);
+    }
+    return true;
+  };
+  // cv[m], Cj[m][LDC] at vv (constraints.py:59-137); wave 0
+  auto eval_constraints = [&](const double* vv, double* cvo, double* Cjo) {
+    if (m == 0) return;
+    const int npairs = k.prob.constraint_kind == CTR_CONS_DIMER ? 1
+                     : k.prob.constraint_kind == CTR_CONS_TRIMER ? 3 : 6;
+    double d2[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      d2[q] = 0.;
+      const int i0 = (q == 0 || q == 2 || q == 4) ? 0 : (q == 5 ? 2 : 1);
+      const int i1 = q == 0 ? 1 : (q <= 2 ? 2 : 3);
+      if (q < npairs) {
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+          const double t = (par(vv, i0, 2 + a) - par(vv, i1, 2 + a)) / k.prob.constraint_dist[a];
+          d2[q] += t * t;
+        }
+      }
+    }
+    for (int e = lane; e < m * LDC; e += WAVE) Cjo[e] = 0.;
+    wsync();
+    const int q = lane;
+    if (q < npairs) {
+      int rank = q;
+      double mine = 0.;
+#pragma unroll
+      for (int p = 0; p < 6; ++p) if (p == q) mine = d2[p];
+      if (k.prob.constraint_kind == CTR_CONS_TETRAMER && ND == 2) {
+        rank = 0;  // stable rank among the 6 squared distances (constraints.py:112)
+#pragma unroll
+        for (int p = 0; p < 6; ++p) rank += (d2[p] < mine || (d2[p] == mine && p < q)) ? 1 : 0;
+      }
+      if (rank < m) {
+        const int i0 = (q == 0 || q == 2 || q == 4) ? 0 : (q == 5 ? 2 : 1);
+        const int i1 = q == 0 ? 1 : (q <= 2 ? 2 : 3);
+        cvo[rank] = 1. - mine;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+          const int kk = 2 + a, b = L.var_of[kk];
+          if (b < 0) continue;
+          const double da = k.prob.constraint_dist[a];
+          const double t = -2. * (par(vv, i0, kk) - par(vv, i1, kk)) / (da * da);
+          Cjo[rank * LDC + b + (L.per_feat[kk] ? i0 : 0)] += t;
+          Cjo[rank * LDC + b + (L.per_feat[kk] ? i1 : 0)] -= t;
+        }
+      }
+    }
+    wsync();
+  };
+
+  // ---- set-up (all threads) ---------------------------------------------------------
+  bool finite = true;
+  for (int e = tid; e < n * NP; e += WAVE * W) {
+    const double x = params[e];
+    pout[e] = x;  // failures keep their input (refine.py:408-418)
+    cur[(e / NP) * CTR_MAX_PARAMS + (e % NP)] = x;
+    if (!isfinite(x)) finite = false;
+  }
+  for (int e = tid; e < W * SM::ROWS; e += WAVE * W) smem[SM::o_rows + e] = 0.;
+  for (int e = tid; e < n * 3; e += WAVE * W) {
+    const int i = e / 3, a = e % 3;
+    mco[e] = a < ND ? params[i * NP + 2 + a] : 0.;
+  }
+  {
+    const double* low = k.low + (size_t)f0 * NP;
+    const double* high = k.high + (size_t)f0 * NP;
+#pragma unroll
+    for (int kk = 0; kk < NP; ++kk) {
+      const int b = L.var_of[kk];
+      if (b < 0) continue;
+      if (L.per_feat[kk]) {
+        for (int i = tid; i < n; i += WAVE * W) {
+          v0[b + i] = params[i * NP + kk];
+          lo[b + i] = low[i * NP + kk];
+          hi[b + i] = high[i * NP + kk];
+        }
+      } else if (tid == 0) {
+        double s = 0., l = INFINITY, h = -INFINITY;
+        for (int i = 0; i < n; ++i) {
+          s += params[i * NP + kk];
+          l = fmin(l, low[i * NP + kk]);
+          h = fmax(h, high[i * NP + kk]);
+        }
+        v0[b] = s / n;
+        lo[b] = l;
+        hi[b] = h;
+      }
+    }
+  }
+  const int nonfinite = __syncthreads_or(!finite ? 1 : 0);
+
+  // state of the solver, meaningful in wave 0 (uniform there)
+  int status = nonfinite ? CTR_STATUS_NONFINITE : (n <= 0 ? CTR_STATUS_OUT_OF_BOUNDS : CTR_STATUS_OK);
+  int round = 0, it = 0, iters = 0, Pround = 0;
+  double mu = 1e-3, nu = 2., sigma = 0., S = 0., pred = 0., cn = 0., rms = NAN;
+  bool last_acc = true;
+  const double fm = k.fmax[k.frame_index[cl]];
+  const double norm = fm * fm / k.prob.residual_factor;  // refine.py:354
+  const double ms2 = k.prob.max_shift * k.prob.max_shift;
+
+  // start of a round (wave 0): window, clipped start vector, derived constants
+  auto begin_round = [&]() -> int {
+    int origin[ND], wshape[ND];
+    if (!window_of(origin, wshape)) { status = CTR_STATUS_OUT_OF_BOUNDS; return BP_FINISH; }
+    bool infeasible = false;
+    for (int i = lane; i < nv; i += WAVE) {
+      if (lo[i] > hi[i]) infeasible = true;
+      const double x = v0[i];
+      vt[i] = x < lo[i] ? lo[i] : (x > hi[i] ? hi[i] : x);
+    }
+    if (lane < MAXC) mult[lane] = 0.;
+    if (__ballot(infeasible) != 0ull) { status = CTR_STATUS_NO_CONVERGENCE; return BP_FINISH; }
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < ND; ++a) { ctl[1 + a] = origin[a]; ctl[4 + a] = wshape[a]; }
+    }
+    wsync();
+    fill_fpar(vt, size_is_var || round == 0);
+    it = 0;
+    return BP_EVAL_INIT;
+  };
+
+  if (wave == 0) {
+    int ph = status == CTR_STATUS_OK ? begin_round() : BP_FINISH;
+    if (lane == 0) ctl[0] = ph;
+  }
+  __syncthreads();
+
+  v4d acc[SM::NTILE];
+  while (true) {
+    const int phase = ctl[0];
+    if (phase == BP_FINISH) break;
+    double Sloc = 0.;
+    int P = 0;
+    if (phase == BP_EVAL_INIT || phase == BP_EVAL_TRIAL) {
+      // ---- all waves: their share of the window at vt ----------------------------------
+      int origin[ND], wshape[ND];
+#pragma unroll
+      for (int a = 0; a < ND; ++a) { origin[a] = ctl[1 + a]; wshape[a] = ctl[4 + a]; }
+      const int w1 = wshape[ND - 2], w2 = wshape[ND - 1];
+      const int npix = (ND == 3 ? wshape[0] : 1) * w1 * w2;
+      const int bgvar = L.var_of[0];
+      const double bg = par(vt, 0, 0);
+      const float inv_w2 = 1.f / (float)w2, inv_w1 = 1.f / (float)w1;
+      const bool big_window = npix >= (1 << 21);
+#pragma unroll
+      for (int t = 0; t < SM::NTILE; ++t) acc[t] = v4d{0., 0., 0., 0.};
+      double* row = myrows + lane * SM::RS;
+      for (int base = wave * WAVE; base < npix; base += WAVE * W) {
+        const int q = base + lane;
+        const bool valid = q < npix;
+        int idx[ND];
+        size_t off;
+        {
+          // q / w2 through the float reciprocal: exact for q < 2^21 (q + 0.5 is never
+          // within 0.5 / w2 of a multiple of w2, far above the float rounding error)
+          const int t = big_window ? q / w2 : (int)(((float)q + 0.5f) * inv_w2);
+          const int x = q - t * w2;
+          if (ND == 3) {
+            const int z = big_window ? t / w1 : (int)(((float)t + 0.5f) * inv_w1);
+            const int y = t - z * w1;
+            idx[0] = z; idx[1] = y; idx[ND - 1] = x;
+            off = ((size_t)(z + origin[0]) * fshape[1] + (y + origin[1])) * fshape[ND - 1] + (x + origin[ND - 1]);
+          } else {
+            idx[0] = t; idx[ND - 1] = x;
+            off = (size_t)(t + origin[0]) * fshape[ND - 1] + (x + origin[ND - 1]);
+          }
+        }
+        bool any = false;
+        double res = 0.;
+        double shared[CTR_MAX_PARAMS];
+#pragma unroll
+        for (int kk = 0; kk < CTR_MAX_PARAMS; ++kk) shared[kk] = 0.;
+        for (int i = 0; i < n; ++i) {
+          double d[1 + ND + NSZ];
+#pragma unroll
+          for (int t = 0; t < 1 + ND + NSZ; ++t) d[t] = 0.;
+          bool in = false;
+          if (valid) {
+            double rel[ND];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) rel[a] = mco[i * 3 + a] - (double)origin[a];
+            in = in_mask<ND>(idx, rel, inv_r2, radius);
+          }
+          if (in) {
+            const double* f = fpar + i * FP;
+            if (!any) {
+              any = true;
+              res = load_pixel(frame, k.frame_dtype, off) - bg;
+            }
+            double r2 = 0., dd[ND];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              dd[a] = (double)(idx[a] + origin[a]) - f[1 + a];
+              r2 += dd[a] * dd[a] * f[4 + a];
+            }
+            const double gv = exp(-0.5 * ND * r2);  // fitfunc.py:112-118
+            const double sig = f[0];
+            const double sdg = sig * (0.5 * ND) * gv;  // -signal * dg/dr2
+            res -= sig * gv;
+            d[0] = -gv;
+            double q2 = 0.;
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              d[1 + a] = sdg * (-dd[a] * f[7 + a]);
+              if (ISO) q2 += dd[a] * dd[a];
+              else d[1 + ND + a] = sdg * (dd[a] * dd[a] * f[10 + a]);
+            }
+            if (ISO) d[1 + ND] = sdg * (q2 * f[10]);
+          }
+#pragma unroll
+          for (int kk = 1; kk < NP; ++kk) {
+            const int b = L.var_of[kk];
+            if (b < 0) continue;
+            if (L.per_feat[kk]) row[b + i] = d[kk - 1];
+            else shared[kk] += d[kk - 1];
+          }
+        }
+        const bool good = any && (res == res);  // nansum (fitfunc.py:449,483)
+#pragma unroll
+        for (int kk = 1; kk < NP; ++kk) {
+          const int b = L.var_of[kk];
+          if (b >= 0 && !L.per_feat[kk]) row[b] = shared[kk];
+        }
+        if (bgvar >= 0) row[bgvar] = good ? -1. : 0.;
+        row[nv] = good ? res : 0.;
+        if (any && !good) {
+          for (int j = 0; j < nv; ++j) row[j] = 0.;
+        }
+        const unsigned long long bal = __ballot(any);
+        P += __popcll(bal);
+        if (good) Sloc += res * res;
+        wsync();
+        if (bal != 0ull) {
+          const int kr = lane >> 4, cc = lane & 15;
+#pragma unroll 4
+          for (int s = 0; s < 16; ++s) {
+            const double* rp = myrows + (4 * s + kr) * SM::RS + cc;
+            double val[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) val[t] = rp[16 * t];
+            int tt = 0;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+              for (int tj = 0; tj <= ti; ++tj) {
+                acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[ti], val[tj], acc[tt], 0, 0, 0);
+                ++tt;
+              }
+          }
+        }
+        wsync();
+      }
+      Sloc = wave_sum(Sloc);
+      if (W > 1) {
+        // partial accumulators meet in LDS: wave w parks its tiles in its own row tile
+        if (wave != 0) {
+#pragma unroll
+          for (int t = 0; t < SM::NTILE; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) myrows[(t * 4 + r) * WAVE + lane] = acc[t][r];
+        }
+        if (lane == 0) { part[2 * wave] = Sloc; part[2 * wave + 1] = (double)P; }
+      }
+    }
+    STAMP(0);
+    if (W > 1) __syncthreads();
+    STAMP(1);
+
+    if (wave == 0) {
+      // ---- wave 0: sum, accept / reject, next step ---------------------------------------
+      int next = phase;
+      bool failed = false;
+      double St = Sloc;
+      if (phase == BP_EVAL_INIT || phase == BP_EVAL_TRIAL) {
+        if (W > 1) {
+#pragma unroll
+          for (int ww = 1; ww < W; ++ww) {
+            const double* pr = smem + SM::o_rows + ww * SM::ROWS;
+#pragma unroll
+            for (int t = 0; t < SM::NTILE; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[t][r] += pr[(t * 4 + r) * WAVE + lane];
+            St += part[2 * ww];
+            P += (int)part[2 * ww + 1];
+          }
+          wsync();
+          // the parked tiles overwrote columns of the row tiles: clear what rows never rewrite
+          // (columns > nv are read by the MFMA but only feed entries nobody looks at)
+        }
+        eval_constraints(vt, cvt, Cjt);
+      }
+      bool accept = false;
+      if (phase == BP_EVAL_INIT) {
+        if (P == 0) { status = CTR_STATUS_OUT_OF_BOUNDS; failed = true; }
+        else if (!isfinite(St)) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+        mu = 1e-3; nu = 2.; sigma = 0.; last_acc = true;
+        Pround = P;
+        accept = !failed;
+      } else if (phase == BP_EVAL_TRIAL) {
+        double cnt = 0.;
+        for (int r = 0; r < m; ++r) cnt += fabs(cvt[r]);
+        double act = 0.5 * (S - St) + (m ? sigma * (cn - cnt) : 0.);
+        act = bcast0(act);
+        if (isfinite(St) && pred > 0. && act > 0.) {
+          const double rho = act / pred, t = 2. * rho - 1.;
+          const double f = 1. - t * t * t;
+          mu *= f > 1. / 3. ? f : 1. / 3.;
+          nu = 2.;
+          accept = true;
+          last_acc = true;
+        } else {
+          mu *= nu; nu *= 2.; last_acc = false;
+          if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+        }
+      }
+      if (accept) {
+        for (int i = lane; i < nv; i += WAVE) v[i] = vt[i];
+        for (int e = lane; e < m * LDC; e += WAVE) Cj[e] = Cjt[e];
+        if (lane < m) cv[lane] = cvt[lane];
+        // acc -> packed lower triangle; D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+        {
+          const int cc = lane & 15, r0 = lane >> 4;
+          int tt = 0;
+#pragma unroll
+          for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj <= ti; ++tj) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int gi = 16 * ti + r0 + 4 * r, gj = 16 * tj + cc;
+                if (gi >= gj) Mp[tri(gi) + gj] = acc[tt][r];
+              }
+              ++tt;
+            }
+        }
+        S = St;
+        wsync();
+      }
+      STAMP(2);
+      if (!failed && it >= maxiter) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+      bool converged = false;
+      if (!failed) {
+        ++it;
+        ++iters;
+        // active set: fixed if at a bound and the Lagrangian gradient pushes outward
+        int nf = 0;
+        for (int b0 = 0; b0 < nv; b0 += WAVE) {
+          const int i = b0 + lane;
+          bool fre = false;
+          if (i < nv) {
+            double gl = Mp[tri(nv) + i];
+            for (int r = 0; r < m; ++r) gl += Cj[r * LDC + i] * mult[r];
+            const bool fixed = (lo[i] == hi[i]) || (v[i] <= lo[i] && gl > 0.) || (v[i] >= hi[i] && gl < 0.);
+            fre = !fixed;
+          }
+          const unsigned long long bal = __ballot(fre);
+          if (fre) fr[nf + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+          nf += __popcll(bal);
+        }
+        wsync();
+        STAMP(3);
+        bool ok_step = true;
+        bool have_dl = false;
+        if (nf == 0) {
+          converged = true;
+        } else if (NT <= 2 && m == 0) {
+         if constexpr (NT <= 2) {
+          // small unconstrained system: one column per lane, in registers
+          bool is_free = false;
+          if (lane < nv) {
+            const double gl = Mp[tri(nv) + lane];
+            is_free = !((lo[lane] == hi[lane]) || (v[lane] <= lo[lane] && gl > 0.) || (v[lane] >= hi[lane] && gl < 0.));
+          }
+          double x_own;
+          ok_step = column_solve<16 * NT>(Mp, nv, mu, is_free, lane, x_own);
+          if (ok_step && lane < nv) dl[lane] = -x_own;
+          wsync();
+          have_dl = true;
+         }
+        } else {
+          for (int e = lane; e < tri(nf); e += WAVE) {
+            int a = (int)((sqrt(8. * e + 1.) - 1.) * 0.5);
+            while (tri(a + 1) <= e) ++a;
+            while (tri(a) > e) --a;
+            const int b = e - tri(a);
+            double h = Msym(Mp, fr[a], fr[b]);
+            if (a == b) h += mu * (h > 1e-300 ? h : 1.);
+            Hp[e] = h;
+          }
+          wsync();
+          ok_step = chol_factor_w(Hp, dl, nf, lane);  // dl doubles as 1/diag until the step is built
+          if (ok_step) {
+            for (int a = lane; a < nf; a += WAVE) {
+              w[a] = Mp[tri(nv) + fr[a]];
+              for (int r = 0; r < m; ++r) Y[r * LDC + a] = Cj[r * LDC + fr[a]];
+            }
+            wsync();
+            chol_solve_w(Hp, dl, nf, w, 1, 0, lane);
+            if (m) {
+              chol_solve_w(Hp, dl, nf, Y, m, LDC, lane);
+              // (C H^-1 C^T) mult = c - C H^-1 g   (range-space form of the KKT step)
+              if (lane < m * m) {
+                const int r = lane / m, s = lane % m;
+                double t = 0.;
+                for (int a = 0; a < nf; ++a) t += Cj[r * LDC + fr[a]] * Y[s * LDC + a];
+                Sc[r * MAXC + s] = t;
+              }
+              if (lane < m) {
+                double t = cv[lane];
+                for (int a = 0; a < nf; ++a) t -= Cj[lane * LDC + fr[a]] * w[a];
+                mult[lane] = t;
+              }
+              wsync();
+              if (lane == 0) {
+                double tr = 0.;
+                for (int r = 0; r < m; ++r) tr += Sc[r * MAXC + r];
+                for (int r = 0; r < m; ++r) Sc[r * MAXC + r] += 1e-14 * tr + 1e-300;
+                bool okc = true;
+                for (int j = 0; j < m && okc; ++j) {
+                  double d = Sc[j * MAXC + j];
+                  for (int q = 0; q < j; ++q) d -= Sc[j * MAXC + q] * Sc[j * MAXC + q];
+                  if (!(d > 0.) || !isfinite(d)) { okc = false; break; }
+                  d = sqrt(d);
+                  Sc[j * MAXC + j] = d;
+                  for (int i = j + 1; i < m; ++i) {
+                    double s = Sc[i * MAXC + j];
+                    for (int q = 0; q < j; ++q) s -= Sc[i * MAXC + q] * Sc[j * MAXC + q];
+                    Sc[i * MAXC + j] = s / d;
+                  }
+                }
+                if (okc) {
+                  for (int i = 0; i < m; ++i) {
+                    double s = mult[i];
+                    for (int q = 0; q < i; ++q) s -= Sc[i * MAXC + q] * mult[q];
+                    mult[i] = s / Sc[i * MAXC + i];
+                  }
+                  for (int i = m - 1; i >= 0; --i) {
+                    double s = mult[i];
+                    for (int q = i + 1; q < m; ++q) s -= Sc[q * MAXC + i] * mult[q];
+                    mult[i] = s / Sc[i * MAXC + i];
+                  }
+                } else {
+                  for (int i = 0; i < m; ++i) mult[i] = 0.;
+                }
+                flag[0] = okc ? 1. : 0.;
+              }
+              wsync();
+              ok_step = flag[0] != 0.;
+            }
+          }
+        }
+        STAMP(4);
+        if (!converged) {
+          if (!ok_step) {
+            mu *= nu; nu *= 2.; last_acc = false;
+            if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+            next = BP_STEP_ONLY;
+          } else {
+            if (!have_dl) {
+              for (int i = lane; i < nv; i += WAVE) dl[i] = 0.;
+              wsync();
+              for (int a = lane; a < nf; a += WAVE) {
+                double t = w[a];
+                for (int r = 0; r < m; ++r) t += Y[r * LDC + a] * mult[r];
+                dl[fr[a]] = -t;
+              }
+              wsync();
+            }
+            double stepmax = 0.;
+            for (int i = lane; i < nv; i += WAVE) {
+              double t = v[i] + dl[i];
+              t = t < lo[i] ? lo[i] : (t > hi[i] ? hi[i] : t);
+              vt[i] = t;
+              const double d = t - v[i];
+              dl[i] = d;
+              stepmax = fmax(stepmax, fabs(d) / (fabs(v[i]) + 1.));
+            }
+            wsync();
+            stepmax = wave_max(stepmax);
+            double partial = 0.;
+            for (int i = lane; i < nv; i += WAVE) {
+              double t = 0.;
+              for (int j = 0; j < nv; ++j) t += Msym(Mp, i, j) * dl[j];
+              partial += dl[i] * (Mp[tri(nv) + i] + 0.5 * t);
+            }
+            pred = -wave_sum(partial);
+            cn = 0.;
+            if (m) {
+              double cn_lin = 0., mmax = 0.;
+              for (int r = 0; r < m; ++r) {
+                double t = cv[r];
+                for (int i = 0; i < nv; ++i) t += Cj[r * LDC + i] * dl[i];
+                cn += fabs(cv[r]);
+                cn_lin += fabs(t);
+                mmax = fmax(mmax, fabs(mult[r]));
+              }
+              if (sigma < 2. * mmax) sigma = 2. * mmax;
+              pred += sigma * (cn - cn_lin);
+            }
+            pred = bcast0(pred);
+            stepmax = bcast0(stepmax);
+            const bool feasible = (m == 0) || (cn <= 1e-10);
+            converged = feasible && ((last_acc && stepmax <= xtol) || pred <= ftol * (0.5 * S) + 1e-300);
+            next = BP_EVAL_TRIAL;
+          }
+        }
+      }
+      STAMP(5);
+      if (failed) next = BP_FINISH;
+      if (converged) {
+        // end of a round: vect_to_params and the shift test (refine.py:379-388)
+        rms = sqrt(((S / (double)Pround) / norm) / k.prob.residual_factor);
+        bool moved = false;
+        for (int i = lane; i < n; i += WAVE) {
+          double d2 = 0.;
+#pragma unroll
+          for (int kk = 0; kk < NP; ++kk) {
+            const int b = L.var_of[kk];
+            if (b >= 0) cur[i * CTR_MAX_PARAMS + kk] = v[b + (L.per_feat[kk] ? i : 0)];
+          }
+#pragma unroll
+          for (int a = 0; a < ND; ++a) {
+            const double d = cur[i * CTR_MAX_PARAMS + 2 + a] - mco[i * 3 + a];
+            d2 += d * d;
+          }
+          if (!(d2 < ms2)) moved = true;
+        }
+        const bool any_moved = __ballot(moved) != 0ull;
+        wsync();
+        ++round;
+        if (!any_moved || round >= k.prob.max_iter) {
+          if (rms > k.prob.max_rms_dev) status = CTR_STATUS_RMS_DEV;  // refine.py:391
+          next = BP_FINISH;
+        } else {
+          for (int e = lane; e < n * 3; e += WAVE) {
+            const int i = e / 3, a = e % 3;
+            if (a < ND) mco[e] = cur[i * CTR_MAX_PARAMS + 2 + a];
+          }
+          wsync();
+          next = begin_round();
+        }
+      } else if (next == BP_EVAL_TRIAL) {
+        fill_fpar(vt, size_is_var);
+      }
+      STAMP(6);
+      if (lane == 0) ctl[0] = next;
+    }
+    __syncthreads();
+    STAMP(7);
+  }
+
+  if (wave == 0) {
+    const bool ok = status == CTR_STATUS_OK;
+    if (ok)
+      for (int e = lane; e < n * NP; e += WAVE) pout[e] = cur[(e / NP) * CTR_MAX_PARAMS + (e % NP)];
+    if (lane == 0) {
+      k.status[cl] = status;
+      k.cost[cl] = ok ? rms : NAN;
+      k.n_rounds[cl] = status == CTR_STATUS_NONFINITE || n <= 0 ? 0
+                     : (ok || status == CTR_STATUS_RMS_DEV ? round : round + 1);
+      k.n_iter[cl] = iters;
+    }
+  }
+}
+
+
+
+#endif  // CTREFINE_BLOCK_KERNEL_H

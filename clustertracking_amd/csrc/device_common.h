@@ -1,0 +1,134 @@
+// device_common.h -- kernel arguments, pixel loads, wave reductions, masks, variable layout
+// Part of the MI355X cluster-refinement engine; included by ctrefine.hip inside its
+// anonymous namespace (device code only, gfx950).
+#ifndef CTREFINE_DEVICE_COMMON_H
+#define CTREFINE_DEVICE_COMMON_H
+
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+constexpr int MAXC = 6;       // equality constraints per cluster
+constexpr int MAXF = 64;      // features per cluster
+constexpr int MAXNT = 8;      // 16*8 = 128 columns >= CTR_MAX_VARS + 1
+constexpr int FP = 14;        // derived per-feature constants (see fill_fpar)
+
+struct KArgs {
+  ctr_problem prob;
+  const void* frames;
+  int32_t frame_dtype;
+  int32_t n_bin;
+  int64_t shape[3];
+  int64_t frame_elems;
+  const int32_t* frame_index;
+  const int32_t* feat_offset;
+  const double* params;
+  const double* low;
+  const double* high;
+  double* params_out;
+  double* cost;
+  int32_t* status;
+  int32_t* n_rounds;
+  int32_t* n_iter;
+  const double* fmax;
+  const int32_t* order;  // cluster ids of this bin
+};
+
+__device__ __forceinline__ size_t dtype_size(int dtype) {
+  return dtype == CTR_DTYPE_U8 ? 1 : (dtype == CTR_DTYPE_U16 || dtype == CTR_DTYPE_I16) ? 2
+       : (dtype == CTR_DTYPE_I32 || dtype == CTR_DTYPE_F32) ? 4 : 8;
+}
+
+__device__ __forceinline__ double load_pixel(const void* base, int dtype, size_t i) {
+  switch (dtype) {
+    case CTR_DTYPE_U8: return (double)((const uint8_t*)base)[i];
+    case CTR_DTYPE_U16: return (double)((const uint16_t*)base)[i];
+    case CTR_DTYPE_I16: return (double)((const int16_t*)base)[i];
+    case CTR_DTYPE_I32: return (double)((const int32_t*)base)[i];
+    case CTR_DTYPE_F32: return (double)((const float*)base)[i];
+    default: return ((const double*)base)[i];
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+__device__ __forceinline__ double wave_max(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o));
+  return x;
+}
+__device__ __forceinline__ double bcast0(double x) { return __shfl(x, 0); }
+
+__device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
+
+struct Layout {
+  int n, nv;
+  int var_of[CTR_MAX_PARAMS];
+  int per_feat[CTR_MAX_PARAMS];
+};
+
+// vect_from_params layout with groups=None (fitfunc.py:207-263)
+__device__ __forceinline__ void make_layout(const ctr_problem& p, int n, Layout& L) {
+  int nv = 0;
+  L.n = n;
+#pragma unroll
+  for (int k = 0; k < CTR_MAX_PARAMS; ++k) {
+    int m = k < p.n_params ? p.modes[k] : CTR_MODE_CONST;
+    if (m == CTR_MODE_CONST) { L.var_of[k] = -1; L.per_feat[k] = 0; }
+    else if (m == CTR_MODE_VAR) { L.var_of[k] = nv; L.per_feat[k] = 1; nv += n; }
+    else { L.var_of[k] = nv; L.per_feat[k] = 0; nv += 1; }
+  }
+  L.nv = nv;
+}
+
+// ---- masks (refine.py:43-44) --------------------------------------------------
+
+template <int ND>
+__device__ __forceinline__ bool in_mask_exact(const int (&idx)[ND], const double (&rel)[ND],
+                                              const int (&radius)[ND]) {
+#pragma clang fp contract(off)
+  double s = 0.;
+#pragma unroll
+  for (int a = 0; a < ND; ++a) {
+    double t = ((double)idx[a] - rel[a]) / (double)radius[a];
+    double t2 = t * t;
+    s = s + t2;
+  }
+  return s <= 1.;
+}
+
+// Cheap test first; the IEEE-division form only where the two could disagree.
+template <int ND>
+__device__ __forceinline__ bool in_mask(const int (&idx)[ND], const double (&rel)[ND],
+                                        const double (&inv_r2)[ND], const int (&radius)[ND]) {
+  double s = 0.;
+#pragma unroll
+  for (int a = 0; a < ND; ++a) {
+    double d = (double)idx[a] - rel[a];
+    s += d * d * inv_r2[a];
+  }
+  if (fabs(s - 1.) > 1e-9) return s < 1.;
+  return in_mask_exact<ND>(idx, rel, radius);
+}
+
+__device__ __forceinline__ double Msym(const double* Mp, int i, int j) {
+  return i >= j ? Mp[tri(i) + j] : Mp[tri(j) + i];
+}
+
+// ---- equality constraints (constraints.py:59-137) -------------------------------
+
+__device__ __forceinline__ int n_constraints(const ctr_problem& p, int n) {
+  switch (p.constraint_kind) {
+    case CTR_CONS_DIMER: return n == 2 ? 1 : 0;
+    case CTR_CONS_TRIMER: return n == 3 ? 3 : 0;
+    case CTR_CONS_TETRAMER: return n == 4 ? (p.ndim == 2 ? 4 : 6) : 0;
+    default: return 0;
+  }
+}
+
+
+
+#endif  // CTREFINE_DEVICE_COMMON_H

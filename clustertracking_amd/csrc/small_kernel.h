@@ -1,0 +1,479 @@
+// small_kernel.h -- refine_small_kernel: singles and pairs, 16/64 lanes per cluster, registers only
+// Part of the MI355X cluster-refinement engine; included by ctrefine.hip inside its
+// anonymous namespace (device code only, gfx950).
+#ifndef CTREFINE_SMALL_KERNEL_H
+#define CTREFINE_SMALL_KERNEL_H
+
+// ---- small clusters: 16 lanes per cluster, everything in registers ------------------
+//
+// Singles and pairs with the default parameter modes (background per cluster,
+// signal and positions per feature, sizes constant: fitfunc.py:356,379-387) are
+// >95 % of the clusters of a typical frame.  For them the normal equations are
+// tiny (4..9 variables), so four clusters share one wavefront: each 16-lane
+// group runs its own LM state machine, accumulates its [J r]^T [J r] in
+// registers, all-reduces it inside the 16-lane DPP row (no LDS, no MFMA padding)
+// and solves it redundantly in registers.  Groups pull clusters from a global
+// work counter, so a slow cluster only delays its own group.
+//
+// Variable order (fitfunc.py:207-263): [bg, s_0.., pos(axis 0)_0.., pos(axis 1)_0.., ...].
+
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+  const long long b = __double_as_longlong(x);
+  int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// all-reduce inside each 16-lane DPP row
+__device__ __forceinline__ double row_sum(double x) {
+  x += dpp_f64<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += dpp_f64<0x4E>(x);   // quad_perm [2,3,0,1]
+  x += dpp_f64<0x141>(x);  // row_half_mirror
+  x += dpp_f64<0x140>(x);  // row_mirror
+  return x;
+}
+// all-reduce inside a group of SG lanes (16 = one DPP row, 64 = the whole wave)
+template <int SG>
+__device__ __forceinline__ double group_sum(double x) {
+  x = row_sum(x);
+  if (SG == 64) {
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+  }
+  return x;
+}
+
+enum { PH_FETCH = 0, PH_EVAL_INIT = 1, PH_EVAL_TRIAL = 2, PH_STEP_ONLY = 3, PH_DONE = 4 };
+
+// SG = lanes per cluster: 16 (four clusters per wave; singles) or 64 (pairs: a
+// quarter of the per-iteration latency, which is what bounds the slowest pair).
+template <int ND, int NF, bool ISO, int SG>
+__global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* __restrict__ counter) {
+  constexpr int NV = 1 + NF * (1 + ND);
+  constexpr int NR = NV + 1;               // row length incl. the residual
+  constexpr int NM = NR * (NR + 1) / 2;    // packed upper triangle
+  constexpr int NP = 2 + ND + (ISO ? 1 : ND);
+  const int lane = threadIdx.x, sub = lane & (SG - 1), grp = lane / SG;
+  // per group: Mcur[NM] v0[NV] lo[NV] hi[NV]
+  constexpr int GS = NM + 3 * NV;
+  __shared__ double lds[(WAVE / SG) * GS];
+  double* Mcur = lds + grp * GS;
+  double* v0 = Mcur + NM;
+  double* lo = v0 + NV;
+  double* hi = lo + NV;
+
+  const int maxiter = k.prob.solver_maxiter > 0 ? k.prob.solver_maxiter : 100;
+  const double xtol = k.prob.xtol > 0 ? k.prob.xtol : 1e-9;
+  const double ftol = k.prob.ftol > 0 ? k.prob.ftol : 1e-14;
+  const double ms2 = k.prob.max_shift * k.prob.max_shift;
+  double inv_r2[ND];
+  int radius[ND];
+#pragma unroll
+  for (int a = 0; a < ND; ++a) {
+    radius[a] = k.prob.radius[a];
+    inv_r2[a] = 1. / ((double)radius[a] * (double)radius[a]);
+  }
+  long fshape[ND];
+#pragma unroll
+  for (int a = 0; a < ND; ++a) fshape[a] = k.shape[a];
+
+  // per-group state (replicated in the group's 16 lanes)
+  int phase = PH_FETCH, cl = -1, f0 = 0;
+  int round = 0, it = 0, iters = 0, status = CTR_STATUS_OK, Pround = 0;
+  int origin[ND], wshape[ND], npix = 0;
+  double v[NV], vt[NV];
+  double mco[NF][ND], isz2[NF][ND], cst[NF][CTR_MAX_PARAMS];  // mask centres, 1/size^2, p0 rows
+  double mu = 1e-3, nu = 2., S = 0., pred = 0., norm = 1., rms = NAN;
+  bool last_acc = true;
+  const char* frame = nullptr;
+
+  while (true) {
+    // ---- 1. idle groups pull the next cluster -----------------------------------
+    if (phase == PH_FETCH) {
+      int id = 0;
+      if (sub == 0) id = atomicAdd(counter, 1);
+      id = __shfl(id, lane & ~(SG - 1));
+      if (id >= k.n_bin) {
+        phase = PH_DONE;
+      } else {
+        cl = k.order[id];
+        f0 = k.feat_offset[cl];
+        const double* params = k.params + (size_t)f0 * NP;
+        const double* low = k.low + (size_t)f0 * NP;
+        const double* high = k.high + (size_t)f0 * NP;
+        bool finite = true;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+#pragma unroll
+          for (int kk = 0; kk < CTR_MAX_PARAMS; ++kk) {
+            cst[i][kk] = kk < NP ? params[i * NP + kk] : 0.;
+            if (!isfinite(cst[i][kk])) finite = false;
+          }
+#pragma unroll
+          for (int a = 0; a < ND; ++a) {
+            mco[i][a] = cst[i][2 + a];
+            const double sz = cst[i][ISO ? 2 + ND : 2 + ND + a];
+            isz2[i][a] = 1. / (sz * sz);
+          }
+        }
+        // start vector: mean background (refine.py:361), loosest background bound (fitfunc.py:554-557)
+        if (sub == 0) {
+          double sb = 0., lb = INFINITY, hb = -INFINITY;
+#pragma unroll
+          for (int i = 0; i < NF; ++i) {
+            sb += cst[i][0];
+            lb = fmin(lb, low[i * NP]);
+            hb = fmax(hb, high[i * NP]);
+            v0[1 + i] = cst[i][1];
+            lo[1 + i] = low[i * NP + 1];
+            hi[1 + i] = high[i * NP + 1];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              v0[1 + NF + a * NF + i] = cst[i][2 + a];
+              lo[1 + NF + a * NF + i] = low[i * NP + 2 + a];
+              hi[1 + NF + a * NF + i] = high[i * NP + 2 + a];
+            }
+          }
+          v0[0] = sb / NF;
+          lo[0] = lb;
+          hi[0] = hb;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        frame = (const char*)k.frames + (size_t)k.frame_index[cl] * k.frame_elems * dtype_size(k.frame_dtype);
+        const double fm = k.fmax[k.frame_index[cl]];
+        norm = fm * fm / k.prob.residual_factor;
+        round = 0; iters = 0; status = CTR_STATUS_OK; rms = NAN;
+        phase = PH_EVAL_INIT;
+        if (!finite) { status = CTR_STATUS_NONFINITE; phase = PH_FETCH + 100; }
+      }
+    }
+    // (re)start a round: window from the mask centres, trial = clipped start vector
+    if (phase == PH_EVAL_INIT) {
+      long wlo[ND], whi[ND];
+      bool any = false;
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        long ci[ND];
+        bool ok = true;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+          ci[a] = (long)rint(mco[i][a]);
+          if (!(ci[a] >= -(long)radius[a] && ci[a] < fshape[a] + radius[a])) ok = false;
+        }
+        if (ok) {
+#pragma unroll
+          for (int a = 0; a < ND; ++a) {
+            wlo[a] = (!any || ci[a] < wlo[a]) ? ci[a] : wlo[a];
+            whi[a] = (!any || ci[a] > whi[a]) ? ci[a] : whi[a];
+          }
+          any = true;
+        }
+      }
+      if (!any) {
+        status = CTR_STATUS_OUT_OF_BOUNDS;
+        phase = PH_FETCH + 100;
+      } else {
+        npix = 1;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+          long l = wlo[a] - radius[a], u = whi[a] + radius[a] + 1;
+          l = l < 0 ? 0 : l;
+          u = u > fshape[a] ? fshape[a] : u;
+          origin[a] = (int)l;
+          wshape[a] = (int)(u - l);
+          npix *= wshape[a];
+        }
+        bool infeasible = false;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const double x = v0[j], l = lo[j], h = hi[j];
+          if (l > h) infeasible = true;
+          vt[j] = x < l ? l : (x > h ? h : x);
+        }
+        it = 0;
+        if (infeasible) { status = CTR_STATUS_NO_CONVERGENCE; phase = PH_FETCH + 100; }
+      }
+    }
+    if (__all(phase == PH_DONE)) break;
+
+    // ---- 2. one pass over the window at vt: M = [J r]^T [J r], P ----------------
+    double M[NM];
+#pragma unroll
+    for (int e = 0; e < NM; ++e) M[e] = 0.;
+    int P = 0;
+    const bool evaluating = (phase == PH_EVAL_INIT || phase == PH_EVAL_TRIAL);
+    const int npix_here = evaluating ? npix : 0;
+    {
+      const int w_last = wshape[ND - 1];
+      const float inv_w2 = 1.f / (float)w_last;
+      const float inv_w1 = ND == 3 ? 1.f / (float)wshape[1] : 1.f;
+      const bool big_window = npix >= (1 << 21);
+      const double bg = vt[0];
+      for (int base = 0; __any(base < npix_here); base += SG) {
+        const int q = base + sub;
+        if (q < npix_here) {
+          int idx[ND];
+          size_t off;
+          {
+            const int t = big_window ? q / w_last : (int)(((float)q + 0.5f) * inv_w2);
+            const int x = q - t * w_last;
+            if (ND == 3) {
+              const int z = big_window ? t / wshape[1] : (int)(((float)t + 0.5f) * inv_w1);
+              const int y = t - z * wshape[1];
+              idx[0] = z; idx[1] = y; idx[ND - 1] = x;
+              off = ((size_t)(z + origin[0]) * fshape[1] + (y + origin[1])) * fshape[ND - 1] + (x + origin[ND - 1]);
+            } else {
+              idx[0] = t; idx[ND - 1] = x;
+              off = (size_t)(t + origin[0]) * fshape[ND - 1] + (x + origin[ND - 1]);
+            }
+          }
+          double row[NR];
+#pragma unroll
+          for (int j = 0; j < NR; ++j) row[j] = 0.;
+          bool any = false;
+          double res = 0.;
+#pragma unroll
+          for (int i = 0; i < NF; ++i) {
+            double rel[ND];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) rel[a] = mco[i][a] - (double)origin[a];
+            if (in_mask<ND>(idx, rel, inv_r2, radius)) {
+              any = true;
+              double r2 = 0., dd[ND];
+#pragma unroll
+              for (int a = 0; a < ND; ++a) {
+                dd[a] = (double)(idx[a] + origin[a]) - vt[1 + NF + a * NF + i];
+                r2 += dd[a] * dd[a] * isz2[i][a];
+              }
+              const double gv = exp(-0.5 * ND * r2);
+              const double sig = vt[1 + i];
+              res -= sig * gv;
+              row[1 + i] = -gv;
+              const double sng = -sig * (double)ND * gv;
+#pragma unroll
+              for (int a = 0; a < ND; ++a) row[1 + NF + a * NF + i] = sng * dd[a] * isz2[i][a];
+            }
+          }
+          if (any) {
+            res += load_pixel(frame, k.frame_dtype, off) - bg;
+            ++P;
+            if (res == res) {
+              row[0] = -1.;
+              row[NV] = res;
+              int e = 0;
+#pragma unroll
+              for (int p = 0; p < NR; ++p)
+#pragma unroll
+                for (int c2 = p; c2 < NR; ++c2) { M[e] += row[p] * row[c2]; ++e; }
+            }
+          }
+        }
+      }
+    }
+    if (__any(evaluating)) {
+#pragma unroll
+      for (int e = 0; e < NM; ++e) M[e] = group_sum<SG>(M[e]);
+      P = (int)group_sum<SG>((double)P);
+    }
+
+    // ---- 3. accept / reject, next step, convergence, rounds ---------------------
+    if (phase == PH_EVAL_INIT || phase == PH_EVAL_TRIAL || phase == PH_STEP_ONLY) {
+      const double St = M[NM - 1];
+      bool failed = false;
+      if (phase == PH_EVAL_INIT) {
+        if (P == 0) { status = CTR_STATUS_OUT_OF_BOUNDS; failed = true; }
+        else if (!isfinite(St)) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+        mu = 1e-3; nu = 2.; last_acc = true;
+        Pround = P;
+      }
+      bool accept = phase == PH_EVAL_INIT;
+      if (phase == PH_EVAL_TRIAL) {
+        const double act = 0.5 * (S - St);
+        if (isfinite(St) && pred > 0. && act > 0.) {
+          const double rho = act / pred, t = 2. * rho - 1.;
+          const double f = 1. - t * t * t;
+          mu *= f > 1. / 3. ? f : 1. / 3.;
+          nu = 2.;
+          accept = true;
+          last_acc = true;
+        } else {
+          mu *= nu; nu *= 2.; last_acc = false;
+          if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+        }
+      }
+      if (accept && !failed) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = vt[j];
+        S = St;
+        if (sub == 0) {
+#pragma unroll
+          for (int e = 0; e < NM; ++e) Mcur[e] = M[e];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (!failed && it >= maxiter) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+      bool converged = false;
+      if (!failed) {
+        ++it;
+        ++iters;
+        // Mcur: upper triangle packed row-major over [J r]; g = last column
+        auto Mc = [&](int p, int c2) -> double {
+          const int a = p < c2 ? p : c2, b = p < c2 ? c2 : p;
+          return Mcur[a * NR - (a * (a - 1)) / 2 + (b - a)];
+        };
+        double g[NV];
+#pragma unroll
+        for (int p = 0; p < NV; ++p) g[p] = Mc(p, NV);
+        // active set folded into the system: fixed variables get an identity row
+        bool fixed[NV];
+        int nfree = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const double l = lo[j], h = hi[j];
+          fixed[j] = (l == h) || (v[j] <= l && g[j] > 0.) || (v[j] >= h && g[j] < 0.);
+          nfree += fixed[j] ? 0 : 1;
+        }
+        if (nfree == 0) {
+          converged = true;
+        } else {
+          double L[NV][NV], rhs[NV], dinv[NV];
+          bool okc = true;
+#pragma unroll
+          for (int p = 0; p < NV; ++p) {
+#pragma unroll
+            for (int c2 = 0; c2 <= p; ++c2) {
+              double h = (fixed[p] || fixed[c2]) ? 0. : Mc(p, c2);
+              if (p == c2) h = fixed[p] ? 1. : h + mu * (h > 1e-300 ? h : 1.);
+              L[p][c2] = h;
+            }
+            rhs[p] = fixed[p] ? 0. : g[p];
+          }
+#pragma unroll
+          for (int j = 0; j < NV; ++j) {
+            double d = L[j][j];
+#pragma unroll
+            for (int q2 = 0; q2 < j; ++q2) d -= L[j][q2] * L[j][q2];
+            if (!(d > 0.) || !isfinite(d)) okc = false;
+            const double di = 1. / sqrt(d);
+            dinv[j] = di;
+#pragma unroll
+            for (int i = j + 1; i < NV; ++i) {
+              double s = L[i][j];
+#pragma unroll
+              for (int q2 = 0; q2 < j; ++q2) s -= L[i][q2] * L[j][q2];
+              L[i][j] = s * di;
+            }
+          }
+          if (!okc) {
+            mu *= nu; nu *= 2.; last_acc = false;
+            if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+            phase = PH_STEP_ONLY;
+          } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+              double s = rhs[i];
+#pragma unroll
+              for (int q2 = 0; q2 < i; ++q2) s -= L[i][q2] * rhs[q2];
+              rhs[i] = s * dinv[i];
+            }
+#pragma unroll
+            for (int i = NV - 1; i >= 0; --i) {
+              double s = rhs[i];
+#pragma unroll
+              for (int q2 = i + 1; q2 < NV; ++q2) s -= L[q2][i] * rhs[q2];
+              rhs[i] = s * dinv[i];
+            }
+            double dl[NV], stepmax = 0.;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+              double t = v[j] - rhs[j];
+              const double l = lo[j], h = hi[j];
+              t = t < l ? l : (t > h ? h : t);
+              vt[j] = t;
+              dl[j] = t - v[j];
+              stepmax = fmax(stepmax, fabs(dl[j]) / (fabs(v[j]) + 1.));
+            }
+            double acc = 0.;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+              double t = 0.;
+#pragma unroll
+              for (int j = 0; j < NV; ++j) t += Mc(i, j) * dl[j];
+              acc += dl[i] * (g[i] + 0.5 * t);
+            }
+            pred = -acc;
+            converged = (last_acc && stepmax <= xtol) || pred <= ftol * (0.5 * S) + 1e-300;
+            phase = PH_EVAL_TRIAL;
+          }
+        }
+      }
+      if (failed) phase = PH_FETCH + 100;
+      if (converged) {
+        // end of a round (refine.py:376-388)
+        rms = sqrt(((S / (double)Pround) / norm) / k.prob.residual_factor);
+        bool moved = false;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          double d2 = 0.;
+#pragma unroll
+          for (int a = 0; a < ND; ++a) {
+            const double d = v[1 + NF + a * NF + i] - mco[i][a];
+            d2 += d * d;
+          }
+          if (!(d2 < ms2)) moved = true;
+        }
+        ++round;
+        if (!moved || round >= k.prob.max_iter) {
+          if (rms > k.prob.max_rms_dev) status = CTR_STATUS_RMS_DEV;
+          phase = PH_FETCH + 100;
+        } else {
+#pragma unroll
+          for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int a = 0; a < ND; ++a) mco[i][a] = v[1 + NF + a * NF + i];
+          phase = PH_EVAL_INIT;
+        }
+      }
+    }
+    // ---- 4. write the outputs of a finished cluster --------------------------------
+    if (phase == PH_FETCH + 100) {
+      double* pout = k.params_out + (size_t)f0 * NP;
+      const bool ok = status == CTR_STATUS_OK;
+      if (sub < NF) {
+        const int i = sub;
+#pragma unroll
+        for (int ii = 0; ii < NF; ++ii)
+          if (ii == i) {
+#pragma unroll
+            for (int kk = 0; kk < NP; ++kk) {
+              double x = cst[ii][kk];
+              if (ok) {
+                if (kk == 0) x = v[0];
+                else if (kk == 1) x = v[1 + ii];
+                else if (kk < 2 + ND) {
+#pragma unroll
+                  for (int a = 0; a < ND; ++a)
+                    if (kk == 2 + a) x = v[1 + NF + a * NF + ii];
+                }
+              }
+              pout[ii * NP + kk] = x;
+            }
+          }
+      }
+      if (sub == 0) {
+        k.status[cl] = status;
+        k.cost[cl] = ok ? rms : NAN;
+        k.n_rounds[cl] = status == CTR_STATUS_NONFINITE ? 0 : (ok || status == CTR_STATUS_RMS_DEV ? round : round + 1);
+        k.n_iter[cl] = iters;
+      }
+      phase = PH_FETCH;
+    }
+  }
+}
+
+
+#endif  // CTREFINE_SMALL_KERNEL_H
