@@ -434,6 +434,13 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
 #pragma unroll
       for (int t = 0; t < SM::NTILE; ++t) acc[t] = v4d{0., 0., 0., 0.};
       double* row = myrows + lane * SM::RS;
+      int pf_base[CTR_MAX_PARAMS], pf_step[CTR_MAX_PARAMS];
+#pragma unroll
+      for (int kk = 0; kk < CTR_MAX_PARAMS; ++kk) {
+        const bool pf = L.var_of[kk] >= 0 && L.per_feat[kk];
+        pf_base[kk] = pf ? L.var_of[kk] : SM::NVP;
+        pf_step[kk] = pf ? 1 : 0;
+      }
       for (int base = wave * WAVE; base < npix; base += WAVE * W) {
         const int q = base + lane;
         const bool valid = q < npix;
@@ -455,6 +462,8 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           }
         }
         bool any = false;
+        // the pixel is fetched up front (its latency hides behind the mask tests)
+        const double pix = valid ? load_pixel(frame, k.frame_dtype, off) : 0.;
         double res = 0.;
         double shared[CTR_MAX_PARAMS];
 #pragma unroll
@@ -474,7 +483,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             const double* f = fpar + i * FP;
             if (!any) {
               any = true;
-              res = load_pixel(frame, k.frame_dtype, off) - bg;
+              res = pix - bg;
             }
             double r2 = 0., dd[ND];
 #pragma unroll
@@ -496,12 +505,12 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             }
             if (ISO) d[1 + ND] = sdg * (q2 * f[10]);
           }
+          // branch-free scatter: columns of constant / shared parameters go to the pad
+          // column of the row (index 16*NT, never read by the MFMA)
 #pragma unroll
           for (int kk = 1; kk < NP; ++kk) {
-            const int b = L.var_of[kk];
-            if (b < 0) continue;
-            if (L.per_feat[kk]) row[b + i] = d[kk - 1];
-            else shared[kk] += d[kk - 1];
+            row[pf_base[kk] + pf_step[kk] * i] = d[kk - 1];
+            shared[kk] += d[kk - 1];
           }
         }
         const bool good = any && (res == res);  // nansum (fitfunc.py:449,483)
@@ -633,33 +642,38 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         ++iters;
         // active set: fixed if at a bound and the Lagrangian gradient pushes outward
         int nf = 0;
-        for (int b0 = 0; b0 < nv; b0 += WAVE) {
-          const int i = b0 + lane;
-          bool fre = false;
-          if (i < nv) {
-            double gl = Mp[tri(nv) + i];
-            for (int r = 0; r < m; ++r) gl += Cj[r * LDC + i] * mult[r];
-            const bool fixed = (lo[i] == hi[i]) || (v[i] <= lo[i] && gl > 0.) || (v[i] >= hi[i] && gl < 0.);
-            fre = !fixed;
+        bool is_free = false;   // of variable `lane` (all that the register solve needs)
+        const bool reg_solve = NT <= 2 && m == 0;
+        if (reg_solve) {
+          if (lane < nv) {
+            const double gl = Mp[tri(nv) + lane];
+            is_free = !((lo[lane] == hi[lane]) || (v[lane] <= lo[lane] && gl > 0.) || (v[lane] >= hi[lane] && gl < 0.));
           }
-          const unsigned long long bal = __ballot(fre);
-          if (fre) fr[nf + __popcll(bal & ((1ull << lane) - 1ull))] = i;
-          nf += __popcll(bal);
+          nf = __popcll(__ballot(is_free));
+        } else {
+          for (int b0 = 0; b0 < nv; b0 += WAVE) {
+            const int i = b0 + lane;
+            bool fre = false;
+            if (i < nv) {
+              double gl = Mp[tri(nv) + i];
+              for (int r = 0; r < m; ++r) gl += Cj[r * LDC + i] * mult[r];
+              const bool fixed = (lo[i] == hi[i]) || (v[i] <= lo[i] && gl > 0.) || (v[i] >= hi[i] && gl < 0.);
+              fre = !fixed;
+            }
+            const unsigned long long bal = __ballot(fre);
+            if (fre) fr[nf + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+            nf += __popcll(bal);
+          }
+          wsync();
         }
-        wsync();
         STAMP(3);
         bool ok_step = true;
         bool have_dl = false;
         if (nf == 0) {
           converged = true;
-        } else if (NT <= 2 && m == 0) {
+        } else if (reg_solve) {
          if constexpr (NT <= 2) {
           // small unconstrained system: one column per lane, in registers
-          bool is_free = false;
-          if (lane < nv) {
-            const double gl = Mp[tri(nv) + lane];
-            is_free = !((lo[lane] == hi[lane]) || (v[lane] <= lo[lane] && gl > 0.) || (v[lane] >= hi[lane] && gl < 0.));
-          }
           double x_own;
           ok_step = column_solve<16 * NT>(Mp, nv, mu, is_free, lane, x_own);
           if (ok_step && lane < nv) dl[lane] = -x_own;
