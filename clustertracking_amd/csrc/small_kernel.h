@@ -230,6 +230,8 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
               off = (size_t)(t + origin[0]) * fshape[ND - 1] + (x + origin[ND - 1]);
             }
           }
+          // fetched first: the load latency hides behind the mask tests and the model
+          const double pix = load_pixel(frame, k.frame_dtype, off);
           double row[NR];
 #pragma unroll
           for (int j = 0; j < NR; ++j) row[j] = 0.;
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
             }
           }
           if (any) {
-            res += load_pixel(frame, k.frame_dtype, off) - bg;
+            res += pix - bg;
             ++P;
             if (res == res) {
               row[0] = -1.;
