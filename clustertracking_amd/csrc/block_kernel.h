@@ -441,6 +441,10 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         pf_base[kk] = pf ? L.var_of[kk] : SM::NVP;
         pf_step[kk] = pf ? 1 : 0;
       }
+      // first tile of an evaluation: write every feature's columns (the row tile was used as
+      // scratch by the solve / the parked accumulators in between)
+      const unsigned long long all_feat = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+      unsigned long long prev_cand = all_feat;
       for (int base = wave * WAVE; base < npix; base += WAVE * W) {
         const int q = base + lane;
         const bool valid = q < npix;
@@ -464,16 +468,54 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         bool any = false;
         // the pixel is fetched up front (its latency hides behind the mask tests)
         const double pix = valid ? load_pixel(frame, k.frame_dtype, off) : 0.;
+        // Which features can touch this tile at all?  Lane l tests the box of feature l
+        // (mask centre +- radius, a superset of its mask) against the extent of the 64
+        // consecutive pixels: one ballot gives the candidates.  Features written by the
+        // previous tile of this wave but not candidates now still get their zeros.
+        unsigned long long cand;
+        {
+          const int q0 = base, q1 = (base + WAVE - 1 < npix ? base + WAVE - 1 : npix - 1);
+          int lo_i[ND], hi_i[ND];
+          const int t0 = q0 / w2, t1 = q1 / w2;
+          if (ND == 3) {
+            const int z0 = t0 / w1, z1 = t1 / w1;
+            lo_i[0] = z0; hi_i[0] = z1;
+            const bool same_z = z0 == z1;
+            lo_i[1] = same_z ? t0 - z0 * w1 : 0;
+            hi_i[1] = same_z ? t1 - z1 * w1 : w1 - 1;
+            const bool same_row = t0 == t1;
+            lo_i[ND - 1] = same_row ? q0 - t0 * w2 : 0;
+            hi_i[ND - 1] = same_row ? q1 - t1 * w2 : w2 - 1;
+          } else {
+            lo_i[0] = t0; hi_i[0] = t1;
+            const bool same_row = t0 == t1;
+            lo_i[ND - 1] = same_row ? q0 - t0 * w2 : 0;
+            hi_i[ND - 1] = same_row ? q1 - t1 * w2 : w2 - 1;
+          }
+          bool hit = lane < n;
+          if (hit) {
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              const double ca = mco[lane * 3 + a] - (double)origin[a];
+              hit = hit && ((double)hi_i[a] >= ca - (double)radius[a]) && ((double)lo_i[a] <= ca + (double)radius[a]);
+            }
+          }
+          cand = __ballot(hit);
+        }
+        unsigned long long todo = cand | prev_cand;
+        prev_cand = cand;
         double res = 0.;
         double shared[CTR_MAX_PARAMS];
 #pragma unroll
         for (int kk = 0; kk < CTR_MAX_PARAMS; ++kk) shared[kk] = 0.;
-        for (int i = 0; i < n; ++i) {
+        while (todo != 0ull) {
+          const int i = __builtin_ctzll(todo);
+          todo &= todo - 1ull;
           double d[1 + ND + NSZ];
 #pragma unroll
           for (int t = 0; t < 1 + ND + NSZ; ++t) d[t] = 0.;
           bool in = false;
-          if (valid) {
+          if (valid && ((cand >> i) & 1ull)) {
             double rel[ND];
 #pragma unroll
             for (int a = 0; a < ND; ++a) rel[a] = mco[i * 3 + a] - (double)origin[a];
