@@ -446,28 +446,6 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
       const unsigned long long all_feat = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
       unsigned long long prev_cand = all_feat;
       for (int base = wave * WAVE; base < npix; base += WAVE * W) {
-        const int q = base + lane;
-        const bool valid = q < npix;
-        int idx[ND];
-        size_t off;
-        {
-          // q / w2 through the float reciprocal: exact for q < 2^21 (q + 0.5 is never
-          // within 0.5 / w2 of a multiple of w2, far above the float rounding error)
-          const int t = big_window ? q / w2 : (int)(((float)q + 0.5f) * inv_w2);
-          const int x = q - t * w2;
-          if (ND == 3) {
-            const int z = big_window ? t / w1 : (int)(((float)t + 0.5f) * inv_w1);
-            const int y = t - z * w1;
-            idx[0] = z; idx[1] = y; idx[ND - 1] = x;
-            off = ((size_t)(z + origin[0]) * fshape[1] + (y + origin[1])) * fshape[ND - 1] + (x + origin[ND - 1]);
-          } else {
-            idx[0] = t; idx[ND - 1] = x;
-            off = (size_t)(t + origin[0]) * fshape[ND - 1] + (x + origin[ND - 1]);
-          }
-        }
-        bool any = false;
-        // the pixel is fetched up front (its latency hides behind the mask tests)
-        const double pix = valid ? load_pixel(frame, k.frame_dtype, off) : 0.;
         // Which features can touch this tile at all?  Lane l tests the box of feature l
         // (mask centre +- radius, a superset of its mask) against the extent of the 64
         // consecutive pixels: one ballot gives the candidates.  Features written by the
@@ -502,6 +480,29 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           }
           cand = __ballot(hit);
         }
+        if ((cand | prev_cand) == 0ull) continue;  // nothing to compute, nothing to clear
+        const int q = base + lane;
+        const bool valid = q < npix;
+        int idx[ND];
+        size_t off;
+        {
+          // q / w2 through the float reciprocal: exact for q < 2^21 (q + 0.5 is never
+          // within 0.5 / w2 of a multiple of w2, far above the float rounding error)
+          const int t = big_window ? q / w2 : (int)(((float)q + 0.5f) * inv_w2);
+          const int x = q - t * w2;
+          if (ND == 3) {
+            const int z = big_window ? t / w1 : (int)(((float)t + 0.5f) * inv_w1);
+            const int y = t - z * w1;
+            idx[0] = z; idx[1] = y; idx[ND - 1] = x;
+            off = ((size_t)(z + origin[0]) * fshape[1] + (y + origin[1])) * fshape[ND - 1] + (x + origin[ND - 1]);
+          } else {
+            idx[0] = t; idx[ND - 1] = x;
+            off = (size_t)(t + origin[0]) * fshape[ND - 1] + (x + origin[ND - 1]);
+          }
+        }
+        bool any = false;
+        // the pixel is fetched up front (its latency hides behind the mask tests)
+        const double pix = (valid && cand != 0ull) ? load_pixel(frame, k.frame_dtype, off) : 0.;
         unsigned long long todo = cand | prev_cand;
         prev_cand = cand;
         double res = 0.;
