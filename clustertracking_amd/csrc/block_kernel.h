@@ -57,11 +57,11 @@ __device__ __forceinline__ bool column_solve(const double* Mp, int nv, double mu
   for (int i = 0; i < NR; ++i) {
     const bool rowv = ((fmask >> i) & 1ull) != 0ull;
     double x = 0.;
-    if (rowv && colv) x = Msym(Mp, i, c);
+    if (rowv && colv) x = Msym(Mp, i + 1, c + 1);
     if (i == c) x = colv ? x + mu * (x > 1e-300 ? x : 1.) : 1.;
     col[i] = x;
   }
-  double y = colv ? Mp[tri(nv) + c] : 0.;
+  double y = colv ? Mp[tri(c + 1)] : 0.;
   double mydinv = 1., yown = 0.;
   bool ok = true;
 #pragma unroll
@@ -92,6 +92,43 @@ __device__ __forceinline__ bool column_solve(const double* Mp, int nv, double mu
     }
   }
   return ok;
+}
+
+// Internal column order of the block kernel's [r J] matrix: column 0 is the
+// residual, then the shared variables (background, any 'cluster'-mode column), then
+// the per-feature variables FEATURE-MAJOR, so that a feature occupies one (at most
+// two) 16-column MFMA blocks and a pixel tile only pays for the blocks of its
+// candidate features.  Variable c lives in column c + 1.  (The reference's
+// parameter-major order, fitfunc.py:207-263, is an external convention only: the
+// engine's inputs and outputs are parameter tables.)
+struct LayoutB {
+  int n, nv, nshared, npf;
+  int slot[CTR_MAX_PARAMS];     // rank among the shared / per-feature variables, -1 if constant
+  int per_feat[CTR_MAX_PARAMS];
+  __device__ __forceinline__ int vidx(int kk, int i) const {
+    return slot[kk] < 0 ? -1 : (per_feat[kk] ? nshared + i * npf + slot[kk] : slot[kk]);
+  }
+  // bit mask of the 16-column blocks that hold the columns of feature i
+  __device__ __forceinline__ unsigned blocks(int i) const {
+    if (npf == 0) return 0u;
+    const int c0 = 1 + nshared + i * npf, c1 = c0 + npf - 1;
+    return (1u << (c0 >> 4)) | (1u << (c1 >> 4));
+  }
+};
+
+__device__ __forceinline__ void make_layout_b(const ctr_problem& p, int n, LayoutB& L) {
+  int ns = 0, np = 0;
+  L.n = n;
+#pragma unroll
+  for (int k = 0; k < CTR_MAX_PARAMS; ++k) {
+    const int m = k < p.n_params ? p.modes[k] : CTR_MODE_CONST;
+    if (m == CTR_MODE_CONST) { L.slot[k] = -1; L.per_feat[k] = 0; }
+    else if (m == CTR_MODE_VAR) { L.slot[k] = np++; L.per_feat[k] = 1; }
+    else { L.slot[k] = ns++; L.per_feat[k] = 0; }
+  }
+  L.nshared = ns;
+  L.npf = np;
+  L.nv = ns + n * np;
 }
 
 template <int NT, int W>
@@ -210,8 +247,8 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
   int* ctl = (int*)(smem + SM::o_ctl);
   double* myrows = smem + SM::o_rows + wave * SM::ROWS;
 
-  Layout L;
-  make_layout(k.prob, n, L);
+  LayoutB L;
+  make_layout_b(k.prob, n, L);
   const int nv = L.nv;
   const int m = n_constraints(k.prob, n);
   const void* frame = (const char*)k.frames + (size_t)k.frame_index[cl] * k.frame_elems * dtype_size(k.frame_dtype);
@@ -229,15 +266,15 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
   }
   // parameter kk of feature i at vector vv (vect_to_params, fitfunc.py:266-315)
   auto par = [&](const double* vv, int i, int kk) -> double {
-    const int b = L.var_of[kk];
+    const int b = L.vidx(kk, i);
     if (b < 0) return cur[i * CTR_MAX_PARAMS + kk];
-    return vv[b + (L.per_feat[kk] ? i : 0)];
+    return vv[b];
   };
   // derived constants of every feature at vv: [0] signal [1..3] centre
   // [4..6] 1/size^2 [7..9] 2/size^2 [10..12] -2/size^3   (wave 0)
   bool size_is_var = false;
 #pragma unroll
-  for (int kk = 2 + ND; kk < NP; ++kk) size_is_var = size_is_var || L.var_of[kk] >= 0;
+  for (int kk = 2 + ND; kk < NP; ++kk) size_is_var = size_is_var || L.slot[kk] >= 0;
   auto fill_fpar = [&](const double* vv, bool sizes) {
     for (int i = lane; i < n; i += WAVE) {
       double* f = fpar + i * FP;
@@ -324,12 +361,12 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         cvo[rank] = 1. - mine;
 #pragma unroll
         for (int a = 0; a < ND; ++a) {
-          const int kk = 2 + a, b = L.var_of[kk];
-          if (b < 0) continue;
+          const int kk = 2 + a;
+          if (L.slot[kk] < 0) continue;
           const double da = k.prob.constraint_dist[a];
           const double t = -2. * (par(vv, i0, kk) - par(vv, i1, kk)) / (da * da);
-          Cjo[rank * LDC + b + (L.per_feat[kk] ? i0 : 0)] += t;
-          Cjo[rank * LDC + b + (L.per_feat[kk] ? i1 : 0)] -= t;
+          Cjo[rank * LDC + L.vidx(kk, i0)] += t;
+          Cjo[rank * LDC + L.vidx(kk, i1)] -= t;
         }
       }
     }
@@ -354,15 +391,16 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
     const double* high = k.high + (size_t)f0 * NP;
 #pragma unroll
     for (int kk = 0; kk < NP; ++kk) {
-      const int b = L.var_of[kk];
-      if (b < 0) continue;
+      if (L.slot[kk] < 0) continue;
       if (L.per_feat[kk]) {
         for (int i = tid; i < n; i += WAVE * W) {
-          v0[b + i] = params[i * NP + kk];
-          lo[b + i] = low[i * NP + kk];
-          hi[b + i] = high[i * NP + kk];
+          const int b = L.vidx(kk, i);
+          v0[b] = params[i * NP + kk];
+          lo[b] = low[i * NP + kk];
+          hi[b] = high[i * NP + kk];
         }
       } else if (tid == 0) {
+        const int b = L.vidx(kk, 0);
         double s = 0., l = INFINITY, h = -INFINITY;
         for (int i = 0; i < n; ++i) {
           s += params[i * NP + kk];
@@ -427,7 +465,6 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
       for (int a = 0; a < ND; ++a) { origin[a] = ctl[1 + a]; wshape[a] = ctl[4 + a]; }
       const int w1 = wshape[ND - 2], w2 = wshape[ND - 1];
       const int npix = (ND == 3 ? wshape[0] : 1) * w1 * w2;
-      const int bgvar = L.var_of[0];
       const double bg = par(vt, 0, 0);
       const float inv_w2 = 1.f / (float)w2, inv_w1 = 1.f / (float)w1;
       const bool big_window = npix >= (1 << 21);
@@ -437,9 +474,9 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
       int pf_base[CTR_MAX_PARAMS], pf_step[CTR_MAX_PARAMS];
 #pragma unroll
       for (int kk = 0; kk < CTR_MAX_PARAMS; ++kk) {
-        const bool pf = L.var_of[kk] >= 0 && L.per_feat[kk];
-        pf_base[kk] = pf ? L.var_of[kk] : SM::NVP;
-        pf_step[kk] = pf ? 1 : 0;
+        const bool pf = L.slot[kk] >= 0 && L.per_feat[kk];
+        pf_base[kk] = pf ? 1 + L.nshared + L.slot[kk] : SM::NVP;
+        pf_step[kk] = pf ? L.npf : 0;
       }
       // first tile of an evaluation: write every feature's columns (the row tile was used as
       // scratch by the solve / the parked accumulators in between)
@@ -558,33 +595,61 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         }
         const bool good = any && (res == res);  // nansum (fitfunc.py:449,483)
 #pragma unroll
-        for (int kk = 1; kk < NP; ++kk) {
-          const int b = L.var_of[kk];
-          if (b >= 0 && !L.per_feat[kk]) row[b] = shared[kk];
-        }
-        if (bgvar >= 0) row[bgvar] = good ? -1. : 0.;
-        row[nv] = good ? res : 0.;
+        for (int kk = 1; kk < NP; ++kk)
+          if (L.slot[kk] >= 0 && !L.per_feat[kk]) row[1 + L.slot[kk]] = good ? shared[kk] : 0.;
+        if (L.slot[0] >= 0) row[1 + L.slot[0]] = good ? -1. : 0.;
+        row[0] = good ? res : 0.;
         if (any && !good) {
-          for (int j = 0; j < nv; ++j) row[j] = 0.;
+          for (int j = 1 + L.nshared; j <= nv; ++j) row[j] = 0.;
         }
         const unsigned long long bal = __ballot(any);
         P += __popcll(bal);
         if (good) Sloc += res * res;
         wsync();
         if (bal != 0ull) {
+          // column blocks worth multiplying: block 0 (residual + shared) and the blocks of
+          // the candidate features; everything else in this tile is zero
+          unsigned tilemask = 1u;
+          for (unsigned long long cm = cand; cm != 0ull; cm &= cm - 1ull) tilemask |= L.blocks(__builtin_ctzll(cm));
           const int kr = lane >> 4, cc = lane & 15;
+          const double* rbase = myrows + kr * SM::RS + cc;
+          if (NT == 1) {
 #pragma unroll 4
-          for (int s = 0; s < 16; ++s) {
-            const double* rp = myrows + (4 * s + kr) * SM::RS + cc;
-            double val[NT];
+            for (int s = 0; s < 16; ++s) {
+              const double x = rbase[4 * s * SM::RS];
+              acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc[0], 0, 0, 0);
+            }
+          } else if (tilemask == (1u << NT) - 1u) {
+            // every block is live: all pairs per k-step, one LDS read per block
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) {
+              double val[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) val[t] = rp[16 * t];
+              for (int t = 0; t < NT; ++t) val[t] = rbase[4 * s * SM::RS + 16 * t];
+              int tt = 0;
+#pragma unroll
+              for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = 0; tj <= ti; ++tj) {
+                  acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[ti], val[tj], acc[tt], 0, 0, 0);
+                  ++tt;
+                }
+            }
+          } else {
+            // one (block, block) pair at a time, so that the skip is one uniform branch per pair
             int tt = 0;
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
               for (int tj = 0; tj <= ti; ++tj) {
-                acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[ti], val[tj], acc[tt], 0, 0, 0);
+                if ((((tilemask >> ti) & (tilemask >> tj)) & 1u) != 0u) {
+#pragma unroll 4
+                  for (int s = 0; s < 16; ++s) {
+                    const double xa = rbase[4 * s * SM::RS + 16 * ti];
+                    const double xb = rbase[4 * s * SM::RS + 16 * tj];
+                    acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, xb, acc[tt], 0, 0, 0);
+                  }
+                }
                 ++tt;
               }
           }
@@ -689,7 +754,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         const bool reg_solve = NT <= 2 && m == 0;
         if (reg_solve) {
           if (lane < nv) {
-            const double gl = Mp[tri(nv) + lane];
+            const double gl = Mp[tri(lane + 1)];
             is_free = !((lo[lane] == hi[lane]) || (v[lane] <= lo[lane] && gl > 0.) || (v[lane] >= hi[lane] && gl < 0.));
           }
           nf = __popcll(__ballot(is_free));
@@ -698,7 +763,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             const int i = b0 + lane;
             bool fre = false;
             if (i < nv) {
-              double gl = Mp[tri(nv) + i];
+              double gl = Mp[tri(i + 1)];
               for (int r = 0; r < m; ++r) gl += Cj[r * LDC + i] * mult[r];
               const bool fixed = (lo[i] == hi[i]) || (v[i] <= lo[i] && gl > 0.) || (v[i] >= hi[i] && gl < 0.);
               fre = !fixed;
@@ -729,7 +794,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             while (tri(a + 1) <= e) ++a;
             while (tri(a) > e) --a;
             const int b = e - tri(a);
-            double h = Msym(Mp, fr[a], fr[b]);
+            double h = Msym(Mp, fr[a] + 1, fr[b] + 1);
             if (a == b) h += mu * (h > 1e-300 ? h : 1.);
             Hp[e] = h;
           }
@@ -737,7 +802,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           ok_step = chol_factor_w(Hp, dl, nf, lane);  // dl doubles as 1/diag until the step is built
           if (ok_step) {
             for (int a = lane; a < nf; a += WAVE) {
-              w[a] = Mp[tri(nv) + fr[a]];
+              w[a] = Mp[tri(fr[a] + 1)];
               for (int r = 0; r < m; ++r) Y[r * LDC + a] = Cj[r * LDC + fr[a]];
             }
             wsync();
@@ -826,8 +891,8 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             double partial = 0.;
             for (int i = lane; i < nv; i += WAVE) {
               double t = 0.;
-              for (int j = 0; j < nv; ++j) t += Msym(Mp, i, j) * dl[j];
-              partial += dl[i] * (Mp[tri(nv) + i] + 0.5 * t);
+              for (int j = 0; j < nv; ++j) t += Msym(Mp, i + 1, j + 1) * dl[j];
+              partial += dl[i] * (Mp[tri(i + 1)] + 0.5 * t);
             }
             pred = -wave_sum(partial);
             cn = 0.;
@@ -861,8 +926,8 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           double d2 = 0.;
 #pragma unroll
           for (int kk = 0; kk < NP; ++kk) {
-            const int b = L.var_of[kk];
-            if (b >= 0) cur[i * CTR_MAX_PARAMS + kk] = v[b + (L.per_feat[kk] ? i : 0)];
+            const int b = L.vidx(kk, i);
+            if (b >= 0) cur[i * CTR_MAX_PARAMS + kk] = v[b];
           }
 #pragma unroll
           for (int a = 0; a < ND; ++a) {
