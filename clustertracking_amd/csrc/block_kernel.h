@@ -783,7 +783,18 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
          if constexpr (NT <= 2) {
           // small unconstrained system: one column per lane, in registers
           double x_own;
-          ok_step = column_solve<16 * NT>(Mp, nv, mu, is_free, lane, x_own);
+          // unrolled to the next multiple of four rows (the identity rows beyond the
+          // variables would otherwise be eliminated too: work grows with the square)
+          if (NT == 1) {
+            if (nv <= 8) ok_step = column_solve<8>(Mp, nv, mu, is_free, lane, x_own);
+            else if (nv <= 12) ok_step = column_solve<12>(Mp, nv, mu, is_free, lane, x_own);
+            else ok_step = column_solve<16>(Mp, nv, mu, is_free, lane, x_own);
+          } else {
+            if (nv <= 20) ok_step = column_solve<20>(Mp, nv, mu, is_free, lane, x_own);
+            else if (nv <= 24) ok_step = column_solve<24>(Mp, nv, mu, is_free, lane, x_own);
+            else if (nv <= 28) ok_step = column_solve<28>(Mp, nv, mu, is_free, lane, x_own);
+            else ok_step = column_solve<32>(Mp, nv, mu, is_free, lane, x_own);
+          }
           if (ok_step && lane < nv) dl[lane] = -x_own;
           wsync();
           have_dl = true;
