@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
   int round = 0, it = 0, iters = 0, status = CTR_STATUS_OK, Pround = 0;
   int origin[ND], wshape[ND], npix = 0;
   double v[NV], vt[NV];
-  double mco[NF][ND], isz2[NF][ND], cst[NF][CTR_MAX_PARAMS];  // mask centres, 1/size^2, p0 rows
+  double mco[NF][ND], isz2[NF][ND];  // mask centres, 1/size^2 (p0 rows are re-read from HBM when needed)
   double mu = 1e-3, nu = 2., S = 0., pred = 0., norm = 1., rms = NAN;
   bool last_acc = true;
   const char* frame = nullptr;
@@ -107,14 +107,12 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
 #pragma unroll
-          for (int kk = 0; kk < CTR_MAX_PARAMS; ++kk) {
-            cst[i][kk] = kk < NP ? params[i * NP + kk] : 0.;
-            if (!isfinite(cst[i][kk])) finite = false;
-          }
+          for (int kk = 0; kk < NP; ++kk)
+            if (!isfinite(params[i * NP + kk])) finite = false;
 #pragma unroll
           for (int a = 0; a < ND; ++a) {
-            mco[i][a] = cst[i][2 + a];
-            const double sz = cst[i][ISO ? 2 + ND : 2 + ND + a];
+            mco[i][a] = params[i * NP + 2 + a];
+            const double sz = params[i * NP + (ISO ? 2 + ND : 2 + ND + a)];
             isz2[i][a] = 1. / (sz * sz);
           }
         }
@@ -123,15 +121,15 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
           double sb = 0., lb = INFINITY, hb = -INFINITY;
 #pragma unroll
           for (int i = 0; i < NF; ++i) {
-            sb += cst[i][0];
+            sb += params[i * NP];
             lb = fmin(lb, low[i * NP]);
             hb = fmax(hb, high[i * NP]);
-            v0[1 + i] = cst[i][1];
+            v0[1 + i] = params[i * NP + 1];
             lo[1 + i] = low[i * NP + 1];
             hi[1 + i] = high[i * NP + 1];
 #pragma unroll
             for (int a = 0; a < ND; ++a) {
-              v0[1 + NF + a * NF + i] = cst[i][2 + a];
+              v0[1 + NF + a * NF + i] = params[i * NP + 2 + a];
               lo[1 + NF + a * NF + i] = low[i * NP + 2 + a];
               hi[1 + NF + a * NF + i] = high[i * NP + 2 + a];
             }
@@ -452,7 +450,7 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
           if (ii == i) {
 #pragma unroll
             for (int kk = 0; kk < NP; ++kk) {
-              double x = cst[ii][kk];
+              double x = k.params[(size_t)(f0 + ii) * NP + kk];
               if (ok) {
                 if (kk == 0) x = v[0];
                 else if (kk == 1) x = v[1 + ii];
