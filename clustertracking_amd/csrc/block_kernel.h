@@ -46,9 +46,9 @@ __device__ __forceinline__ double readlane_f64(double x, int srclane) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <int NR>
+template <int NR, class QF>
 __device__ __forceinline__ bool column_solve(const double* Mp, int nv, double mu, bool is_free,
-                                             int lane, double& x_own) {
+                                             int lane, double& x_own, bool nwt, QF qvar) {
   const int c = lane;
   const bool colv = c < nv && is_free;
   const unsigned long long fmask = __ballot(colv);
@@ -56,9 +56,14 @@ __device__ __forceinline__ bool column_solve(const double* Mp, int nv, double mu
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     const bool rowv = ((fmask >> i) & 1ull) != 0ull;
-    double x = 0.;
-    if (rowv && colv) x = Msym(Mp, i + 1, c + 1);
-    if (i == c) x = colv ? x + mu * (x > 1e-300 ? x : 1.) : 1.;
+    double x = 0., xq = 0.;
+    if (rowv && colv) {
+      x = Msym(Mp, i + 1, c + 1);
+      if (nwt) xq = qvar(i, c);   // exact second-order part of the model Hessian
+    }
+    // Marquardt scaling by the Gauss-Newton diagonal in both models
+    if (i == c) x = colv ? x + xq + mu * (x > 1e-300 ? x : 1.) : 1.;
+    else x += xq;
     col[i] = x;
   }
   double y = colv ? Mp[tri(c + 1)] : 0.;
@@ -131,6 +136,8 @@ __device__ __forceinline__ void make_layout_b(const ctr_problem& p, int n, Layou
   L.nv = ns + n * np;
 }
 
+constexpr int QT = 8;  // second-order sums kept per feature: U[a<=b], 3 (2D) or 6 (3D) used
+
 template <int NT, int W>
 struct SmemB {
   static constexpr int NVP = 16 * NT;
@@ -158,9 +165,14 @@ struct SmemB {
   static constexpr int o_fr = o_small + 64;
   static constexpr int o_part = o_fr + NVP / 2 + 2;     // per wave: S, P
   static constexpr int o_ctl = o_part + 2 * W;          // ints: phase, origin[3], wshape[3]
-  static constexpr int total = o_ctl + 8;
+  // second-order sums of the current point, QT per feature (features with >= 3 variables each)
+  static constexpr int NFQ = (NVP + 2) / 3 < MAXF ? (NVP + 2) / 3 : MAXF;
+  static constexpr int o_uc = o_ctl + 8;
+  static constexpr int o_vinfo = o_uc + NFQ * QT;       // ints: feature and kind of every variable
+  static constexpr int o_cpair = o_vinfo + NVP;         // ints: pair behind constraint r (current, trial)
+  static constexpr int total = o_cpair + MAXC;
   static constexpr size_t bytes = (size_t)total * sizeof(double);
-  static_assert(W == 1 || NTILE * 256 <= ROWS, "partial accumulators must fit a row tile");
+  static_assert(W == 1 || NTILE * 256 + QT * WAVE <= ROWS, "partial accumulators must fit a row tile");
 };
 
 enum { BP_EVAL_INIT = 1, BP_EVAL_TRIAL = 2, BP_STEP_ONLY = 3, BP_FINISH = 4 };
@@ -245,12 +257,21 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
   double *cv = smem + SM::o_small, *cvt = cv + 6, *mult = cv + 12, *Sc = cv + 24, *flag = cv + 60;
   int* fr = (int*)(smem + SM::o_fr);
   int* ctl = (int*)(smem + SM::o_ctl);
+  double* Uc = smem + SM::o_uc;
+  int* vfeat = (int*)(smem + SM::o_vinfo);   // feature of variable c, -1 for a shared one
+  int* vkind = vfeat + SM::NVP;              // 0 signal, 1 + a position axis a, -1 anything else
+  int* cpair = (int*)(smem + SM::o_cpair);   // [0..5] current point, [6..11] trial
   double* myrows = smem + SM::o_rows + wave * SM::ROWS;
 
   LayoutB L;
   make_layout_b(k.prob, n, L);
   const int nv = L.nv;
   const int m = n_constraints(k.prob, n);
+  // the exact second-order terms need signal and positions as per-feature variables (the
+  // default modes); otherwise the model Hessian is J^T J throughout (same rule: oracle solve())
+  bool newton_on = L.slot[1] >= 0 && L.per_feat[1];
+#pragma unroll
+  for (int a = 0; a < ND; ++a) newton_on = newton_on && L.slot[2 + a] >= 0 && L.per_feat[2 + a];
   const void* frame = (const char*)k.frames + (size_t)k.frame_index[cl] * k.frame_elems * dtype_size(k.frame_dtype);
   const int maxiter = k.prob.solver_maxiter > 0 ? k.prob.solver_maxiter : 100;
   const double xtol = k.prob.xtol > 0 ? k.prob.xtol : 1e-9;
@@ -324,7 +345,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
     return true;
   };
   // cv[m], Cj[m][LDC] at vv (constraints.py:59-137); wave 0
-  auto eval_constraints = [&](const double* vv, double* cvo, double* Cjo) {
+  auto eval_constraints = [&](const double* vv, double* cvo, double* Cjo, int* cpo) {
     if (m == 0) return;
     const int npairs = k.prob.constraint_kind == CTR_CONS_DIMER ? 1
                      : k.prob.constraint_kind == CTR_CONS_TRIMER ? 3 : 6;
@@ -359,6 +380,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         const int i0 = (q == 0 || q == 2 || q == 4) ? 0 : (q == 5 ? 2 : 1);
         const int i1 = q == 0 ? 1 : (q <= 2 ? 2 : 3);
         cvo[rank] = 1. - mine;
+        cpo[rank] = q;
 #pragma unroll
         for (int a = 0; a < ND; ++a) {
           const int kk = 2 + a;
@@ -382,6 +404,19 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
     if (!isfinite(x)) finite = false;
   }
   for (int e = tid; e < W * SM::ROWS; e += WAVE * W) smem[SM::o_rows + e] = 0.;
+  for (int c = tid; c < nv; c += WAVE * W) {
+    int fi = -1, kind = -1;
+    if (c >= L.nshared) {
+      fi = (c - L.nshared) / L.npf;
+      const int sl = c - L.nshared - fi * L.npf;
+      if (L.per_feat[1] && sl == L.slot[1]) kind = 0;
+#pragma unroll
+      for (int a = 0; a < ND; ++a)
+        if (L.per_feat[2 + a] && sl == L.slot[2 + a]) kind = 1 + a;
+    }
+    vfeat[c] = fi;
+    vkind[c] = kind;
+  }
   for (int e = tid; e < n * 3; e += WAVE * W) {
     const int i = e / 3, a = e % 3;
     mco[e] = a < ND ? params[i * NP + 2 + a] : 0.;
@@ -418,8 +453,9 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
   // state of the solver, meaningful in wave 0 (uniform there)
   int status = nonfinite ? CTR_STATUS_NONFINITE : (n <= 0 ? CTR_STATUS_OUT_OF_BOUNDS : CTR_STATUS_OK);
   int round = 0, it = 0, iters = 0, Pround = 0;
-  double mu = 1e-3, nu = 2., sigma = 0., S = 0., pred = 0., cn = 0., rms = NAN;
+  double mu = 1e-3, nu = 2., sigma = 0., tau = 1., S = 0., pred = 0., cn = 0., cn_pred = 0., rms = NAN;
   bool last_acc = true;
+  double gain = INFINITY;  // relative merit decrease of the last accepted step
   const double fm = k.fmax[k.frame_index[cl]];
   const double norm = fm * fm / k.prob.residual_factor;  // refine.py:354
   const double ms2 = k.prob.max_shift * k.prob.max_shift;
@@ -453,6 +489,11 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
   __syncthreads();
 
   v4d acc[SM::NTILE];
+  // second-order sums U[a<=b] = sum_p res J_pos_a dE/dpos_b of feature `lane` (this wave's share)
+  constexpr int NUF = ND * (ND + 1) / 2;
+  double uacc[NUF];
+#pragma unroll
+  for (int t = 0; t < NUF; ++t) uacc[t] = 0.;
   while (true) {
     const int phase = ctl[0];
     if (phase == BP_FINISH) break;
@@ -470,6 +511,8 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
       const bool big_window = npix >= (1 << 21);
 #pragma unroll
       for (int t = 0; t < SM::NTILE; ++t) acc[t] = v4d{0., 0., 0., 0.};
+#pragma unroll
+      for (int t = 0; t < NUF; ++t) uacc[t] = 0.;
       double* row = myrows + lane * SM::RS;
       int pf_base[CTR_MAX_PARAMS], pf_step[CTR_MAX_PARAMS];
 #pragma unroll
@@ -602,6 +645,36 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         if (any && !good) {
           for (int j = 1 + L.nshared; j <= nv; ++j) row[j] = 0.;
         }
+        if (newton_on && cand != 0ull) {
+          // second pass over the candidates, now that the residual is complete: the lanes'
+          // res * J_pos_a * dE/dpos_b are summed over the tile (four sums per exchange
+          // sequence) and land in the accumulators of lane i = the feature
+          const double resg = good ? res : 0.;
+          for (unsigned long long cm = cand; cm != 0ull; cm &= cm - 1ull) {
+            const int i = __builtin_ctzll(cm);
+            const double* f = fpar + i * FP;
+            double rj[ND], E[ND];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              rj[a] = resg * row[pf_base[2 + a] + pf_step[2 + a] * i];
+              E[a] = (double)ND * (((double)(idx[a] + origin[a]) - f[1 + a]) * f[4 + a]);
+            }
+            if (ND == 2) {
+              const double t = wave_sum4(rj[0] * E[0], rj[0] * E[ND - 1], rj[ND - 1] * E[ND - 1], 0., lane);
+              const double s0 = readlane_f64(t, 0), s1 = readlane_f64(t, 16), s2 = readlane_f64(t, 32);
+              if (lane == i) { uacc[0] += s0; uacc[1] += s1; uacc[NUF - 1] += s2; }
+            } else {
+              const double t = wave_sum4(rj[0] * E[0], rj[0] * E[1], rj[0] * E[ND - 1], rj[1] * E[1], lane);
+              const double t2 = wave_sum4(rj[1] * E[ND - 1], rj[ND - 1] * E[ND - 1], 0., 0., lane);
+              const double s0 = readlane_f64(t, 0), s1 = readlane_f64(t, 16), s2 = readlane_f64(t, 32),
+                           s3 = readlane_f64(t, 48), s4 = readlane_f64(t2, 0), s5 = readlane_f64(t2, 16);
+              if (lane == i) {
+                uacc[0] += s0; uacc[1] += s1; uacc[2 % NUF] += s2;
+                uacc[3 % NUF] += s3; uacc[4 % NUF] += s4; uacc[5 % NUF] += s5;
+              }
+            }
+          }
+        }
         const unsigned long long bal = __ballot(any);
         P += __popcll(bal);
         if (good) Sloc += res * res;
@@ -664,6 +737,8 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           for (int t = 0; t < SM::NTILE; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) myrows[(t * 4 + r) * WAVE + lane] = acc[t][r];
+#pragma unroll
+          for (int t = 0; t < NUF; ++t) myrows[(SM::NTILE * 4 + t) * WAVE + lane] = uacc[t];
         }
         if (lane == 0) { part[2 * wave] = Sloc; part[2 * wave + 1] = (double)P; }
       }
@@ -686,6 +761,8 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             for (int t = 0; t < SM::NTILE; ++t)
 #pragma unroll
               for (int r = 0; r < 4; ++r) acc[t][r] += pr[(t * 4 + r) * WAVE + lane];
+#pragma unroll
+            for (int t = 0; t < NUF; ++t) uacc[t] += pr[(SM::NTILE * 4 + t) * WAVE + lane];
             St += part[2 * ww];
             P += (int)part[2 * ww + 1];
           }
@@ -693,13 +770,13 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           // the parked tiles overwrote columns of the row tiles: clear what rows never rewrite
           // (columns > nv are read by the MFMA but only feed entries nobody looks at)
         }
-        eval_constraints(vt, cvt, Cjt);
+        eval_constraints(vt, cvt, Cjt, cpair + MAXC);
       }
       bool accept = false;
       if (phase == BP_EVAL_INIT) {
         if (P == 0) { status = CTR_STATUS_OUT_OF_BOUNDS; failed = true; }
         else if (!isfinite(St)) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
-        mu = 1e-3; nu = 2.; sigma = 0.; last_acc = true;
+        mu = 1e-3; nu = 2.; sigma = 0.; tau = 1.; last_acc = true; gain = INFINITY;
         Pround = P;
         accept = !failed;
       } else if (phase == BP_EVAL_TRIAL) {
@@ -712,17 +789,26 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           const double f = 1. - t * t * t;
           mu *= f > 1. / 3. ? f : 1. / 3.;
           nu = 2.;
+          gain = act / (0.5 * S + 1e-300);
+          tau = tau < 0.5 ? 2. * tau : 1.;
           accept = true;
           last_acc = true;
         } else {
           mu *= nu; nu *= 2.; last_acc = false;
+          // the linearised constraints promised more than half of what the trial delivered:
+          // shorten the normal step as well
+          if (m && cnt > cn_pred + 0.5 * (cn - cn_pred)) tau *= 0.5;
           if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
         }
       }
       if (accept) {
         for (int i = lane; i < nv; i += WAVE) v[i] = vt[i];
         for (int e = lane; e < m * LDC; e += WAVE) Cj[e] = Cjt[e];
-        if (lane < m) cv[lane] = cvt[lane];
+        if (lane < m) { cv[lane] = cvt[lane]; cpair[lane] = cpair[MAXC + lane]; }
+        if (newton_on && lane < n) {
+#pragma unroll
+          for (int t = 0; t < NUF; ++t) Uc[lane * QT + t] = uacc[t];
+        }
         // acc -> packed lower triangle; D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
         {
           const int cc = lane & 15, r0 = lane >> 4;
@@ -743,9 +829,15 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         wsync();
       }
       STAMP(2);
-      if (!failed && it >= maxiter) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
       bool converged = false;
-      if (!failed) {
+      if (!failed && it >= maxiter) {
+        // iteration limit: a stationary, feasible point still counts as converged (see solve() of the oracle)
+        double cnow = 0.;
+        for (int r = 0; r < m; ++r) cnow += fabs(cv[r]);
+        if (gain <= CTR_STALL_TOL && cnow <= 1e-10) converged = true;
+        else { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+      }
+      if (!failed && !converged) {
         ++it;
         ++iters;
         // active set: fixed if at a bound and the Lagrangian gradient pushes outward
@@ -775,109 +867,160 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           wsync();
         }
         STAMP(3);
-        bool ok_step = true;
-        bool have_dl = false;
+        bool ok_step = false;
+        const double tiny = ftol * (0.5 * S) + 1e-300;
         if (nf == 0) {
           converged = true;
-        } else if (reg_solve) {
-         if constexpr (NT <= 2) {
-          // small unconstrained system: one column per lane, in registers
-          double x_own;
-          // unrolled to the next multiple of four rows (the identity rows beyond the
-          // variables would otherwise be eliminated too: work grows with the square)
-          if (NT == 1) {
-            if (nv <= 8) ok_step = column_solve<8>(Mp, nv, mu, is_free, lane, x_own);
-            else if (nv <= 12) ok_step = column_solve<12>(Mp, nv, mu, is_free, lane, x_own);
-            else ok_step = column_solve<16>(Mp, nv, mu, is_free, lane, x_own);
-          } else {
-            if (nv <= 20) ok_step = column_solve<20>(Mp, nv, mu, is_free, lane, x_own);
-            else if (nv <= 24) ok_step = column_solve<24>(Mp, nv, mu, is_free, lane, x_own);
-            else if (nv <= 28) ok_step = column_solve<28>(Mp, nv, mu, is_free, lane, x_own);
-            else ok_step = column_solve<32>(Mp, nv, mu, is_free, lane, x_own);
-          }
-          if (ok_step && lane < nv) dl[lane] = -x_own;
-          wsync();
-          have_dl = true;
-         }
         } else {
-          for (int e = lane; e < tri(nf); e += WAVE) {
-            int a = (int)((sqrt(8. * e + 1.) - 1.) * 0.5);
-            while (tri(a + 1) <= e) ++a;
-            while (tri(a) > e) --a;
-            const int b = e - tri(a);
-            double h = Msym(Mp, fr[a] + 1, fr[b] + 1);
-            if (a == b) h += mu * (h > 1e-300 ? h : 1.);
-            Hp[e] = h;
-          }
-          wsync();
-          ok_step = chol_factor_w(Hp, dl, nf, lane);  // dl doubles as 1/diag until the step is built
-          if (ok_step) {
-            for (int a = lane; a < nf; a += WAVE) {
-              w[a] = Mp[tri(fr[a] + 1)];
-              for (int r = 0; r < m; ++r) Y[r * LDC + a] = Cj[r * LDC + fr[a]];
+          // Model Hessian.  First choice: the exact one, J^T J + sum_p r_p d2r_p (signal and
+          // positions of every feature: qvar) + sum_r mult_r d2c_r (ccurv, multipliers of the
+          // last step).  Where that is not positive definite on the free variables, or its
+          // projected step is not a descent step of the model, J^T J is used for this
+          // iteration instead.  Same sequence as solve() of oracle/ctr_oracle.c.
+          double mult0[MAXC];
+#pragma unroll
+          for (int r = 0; r < MAXC; ++r) mult0[r] = r < m ? mult[r] : 0.;
+          cn = 0.;
+          for (int r = 0; r < m; ++r) cn += fabs(cv[r]);
+          double stepmax = 0., sigma_t = sigma;
+          // second-order part between two variables (0 unless both belong to one feature)
+          auto qvar = [&](int gi, int gj) -> double {
+            const int fi = vfeat[gi];
+            if (fi < 0 || fi != vfeat[gj]) return 0.;
+            int ka = vkind[gi], kb = vkind[gj];
+            if (ka < 0 || kb < 0) return 0.;
+            if (ka > kb) { const int t = ka; ka = kb; kb = t; gj = gi; }   // gj: variable of the larger kind
+            const int cs = L.vidx(1, fi);
+            const double sig = v[cs];
+            if (ka == 0) return kb == 0 ? 0. : (sig != 0. ? Mp[tri(gj + 1)] / sig : 0.);
+            const int a2 = ka - 1, b2 = kb - 1;
+            double u = Uc[fi * QT + (a2 * ND - (a2 * (a2 - 1)) / 2 + (b2 - a2))];
+            if (a2 == b2) {
+              const double sz = par(v, fi, ISO ? 2 + ND : 2 + ND + a2);
+              u += -(double)ND / (sz * sz) * sig * Mp[tri(cs + 1)];
             }
-            wsync();
-            chol_solve_w(Hp, dl, nf, w, 1, 0, lane);
-            if (m) {
-              chol_solve_w(Hp, dl, nf, Y, m, LDC, lane);
-              // (C H^-1 C^T) mult = c - C H^-1 g   (range-space form of the KKT step)
-              if (lane < m * m) {
-                const int r = lane / m, s = lane % m;
-                double t = 0.;
-                for (int a = 0; a < nf; ++a) t += Cj[r * LDC + fr[a]] * Y[s * LDC + a];
-                Sc[r * MAXC + s] = t;
+            return u;
+          };
+          // curvature of the constraints between two position variables of the same axis
+          auto ccurv = [&](int gi, int gj) -> double {
+            const int ka = vkind[gi];
+            if (ka < 1 || ka != vkind[gj]) return 0.;
+            const int fi = vfeat[gi], fj = vfeat[gj];
+            const double da = k.prob.constraint_dist[ka - 1];
+            double t = 0.;
+#pragma unroll
+            for (int r = 0; r < MAXC; ++r) {
+              if (r < m) {
+                const int q = cpair[r];
+                const int i0 = (q == 0 || q == 2 || q == 4) ? 0 : (q == 5 ? 2 : 1);
+                const int i1 = q == 0 ? 1 : (q <= 2 ? 2 : 3);
+                const double tr = -2. * mult0[r] / (da * da);
+                if (fi == fj) { if (fi == i0 || fi == i1) t += tr; }
+                else if ((fi == i0 && fj == i1) || (fi == i1 && fj == i0)) t -= tr;
               }
-              if (lane < m) {
-                double t = cv[lane];
-                for (int a = 0; a < nf; ++a) t -= Cj[lane * LDC + fr[a]] * w[a];
-                mult[lane] = t;
+            }
+            return t;
+          };
+#pragma nounroll
+          for (int attempt = newton_on ? 1 : 0; attempt >= 0 && !ok_step; --attempt) {
+            const bool nwt = attempt == 1;
+            bool ok_a = true;
+            bool have_dl = false;
+            if (reg_solve) {
+             if constexpr (NT <= 2) {
+              // small unconstrained system: one column per lane, in registers
+              double x_own;
+              // unrolled to the next multiple of four rows (the identity rows beyond the
+              // variables would otherwise be eliminated too: work grows with the square)
+              if (NT == 1) {
+                if (nv <= 8) ok_a = column_solve<8>(Mp, nv, mu, is_free, lane, x_own, nwt, qvar);
+                else if (nv <= 12) ok_a = column_solve<12>(Mp, nv, mu, is_free, lane, x_own, nwt, qvar);
+                else ok_a = column_solve<16>(Mp, nv, mu, is_free, lane, x_own, nwt, qvar);
+              } else {
+                if (nv <= 20) ok_a = column_solve<20>(Mp, nv, mu, is_free, lane, x_own, nwt, qvar);
+                else if (nv <= 24) ok_a = column_solve<24>(Mp, nv, mu, is_free, lane, x_own, nwt, qvar);
+                else if (nv <= 28) ok_a = column_solve<28>(Mp, nv, mu, is_free, lane, x_own, nwt, qvar);
+                else ok_a = column_solve<32>(Mp, nv, mu, is_free, lane, x_own, nwt, qvar);
+              }
+              if (ok_a && lane < nv) dl[lane] = -x_own;
+              wsync();
+              have_dl = true;
+             }
+            } else {
+              for (int e = lane; e < tri(nf); e += WAVE) {
+                int a = (int)((sqrt(8. * e + 1.) - 1.) * 0.5);
+                while (tri(a + 1) <= e) ++a;
+                while (tri(a) > e) --a;
+                const int b = e - tri(a);
+                double h = Msym(Mp, fr[a] + 1, fr[b] + 1);
+                const double hs = a == b ? mu * (h > 1e-300 ? h : 1.) : 0.;
+                if (nwt) { h += qvar(fr[a], fr[b]); h += ccurv(fr[a], fr[b]); }
+                Hp[e] = h + hs;
               }
               wsync();
-              if (lane == 0) {
-                double tr = 0.;
-                for (int r = 0; r < m; ++r) tr += Sc[r * MAXC + r];
-                for (int r = 0; r < m; ++r) Sc[r * MAXC + r] += 1e-14 * tr + 1e-300;
-                bool okc = true;
-                for (int j = 0; j < m && okc; ++j) {
-                  double d = Sc[j * MAXC + j];
-                  for (int q = 0; q < j; ++q) d -= Sc[j * MAXC + q] * Sc[j * MAXC + q];
-                  if (!(d > 0.) || !isfinite(d)) { okc = false; break; }
-                  d = sqrt(d);
-                  Sc[j * MAXC + j] = d;
-                  for (int i = j + 1; i < m; ++i) {
-                    double s = Sc[i * MAXC + j];
-                    for (int q = 0; q < j; ++q) s -= Sc[i * MAXC + q] * Sc[j * MAXC + q];
-                    Sc[i * MAXC + j] = s / d;
-                  }
+              ok_a = chol_factor_w(Hp, dl, nf, lane);  // dl doubles as 1/diag until the step is built
+              if (ok_a) {
+                for (int a = lane; a < nf; a += WAVE) {
+                  w[a] = Mp[tri(fr[a] + 1)];
+                  for (int r = 0; r < m; ++r) Y[r * LDC + a] = Cj[r * LDC + fr[a]];
                 }
-                if (okc) {
-                  for (int i = 0; i < m; ++i) {
-                    double s = mult[i];
-                    for (int q = 0; q < i; ++q) s -= Sc[i * MAXC + q] * mult[q];
-                    mult[i] = s / Sc[i * MAXC + i];
+                wsync();
+                chol_solve_w(Hp, dl, nf, w, 1, 0, lane);
+                if (m) {
+                  chol_solve_w(Hp, dl, nf, Y, m, LDC, lane);
+                  // (C H^-1 C^T) mult = tau c - C H^-1 g   (range-space form of the KKT step,
+                  // normal step damped: C d = -tau c)
+                  if (lane < m * m) {
+                    const int r = lane / m, s2 = lane % m;
+                    double t = 0.;
+                    for (int a = 0; a < nf; ++a) t += Cj[r * LDC + fr[a]] * Y[s2 * LDC + a];
+                    Sc[r * MAXC + s2] = t;
                   }
-                  for (int i = m - 1; i >= 0; --i) {
-                    double s = mult[i];
-                    for (int q = i + 1; q < m; ++q) s -= Sc[q * MAXC + i] * mult[q];
-                    mult[i] = s / Sc[i * MAXC + i];
+                  if (lane < m) {
+                    double t = tau * cv[lane];
+                    for (int a = 0; a < nf; ++a) t -= Cj[lane * LDC + fr[a]] * w[a];
+                    mult[lane] = t;
                   }
-                } else {
-                  for (int i = 0; i < m; ++i) mult[i] = 0.;
+                  wsync();
+                  if (lane == 0) {
+                    double tr = 0.;
+                    for (int r = 0; r < m; ++r) tr += Sc[r * MAXC + r];
+                    for (int r = 0; r < m; ++r) Sc[r * MAXC + r] += 1e-14 * tr + 1e-300;
+                    bool okc = true;
+                    for (int j = 0; j < m && okc; ++j) {
+                      double d = Sc[j * MAXC + j];
+                      for (int q = 0; q < j; ++q) d -= Sc[j * MAXC + q] * Sc[j * MAXC + q];
+                      if (!(d > 0.) || !isfinite(d)) { okc = false; break; }
+                      d = sqrt(d);
+                      Sc[j * MAXC + j] = d;
+                      for (int i = j + 1; i < m; ++i) {
+                        double s2 = Sc[i * MAXC + j];
+                        for (int q = 0; q < j; ++q) s2 -= Sc[i * MAXC + q] * Sc[j * MAXC + q];
+                        Sc[i * MAXC + j] = s2 / d;
+                      }
+                    }
+                    if (okc) {
+                      for (int i = 0; i < m; ++i) {
+                        double s2 = mult[i];
+                        for (int q = 0; q < i; ++q) s2 -= Sc[i * MAXC + q] * mult[q];
+                        mult[i] = s2 / Sc[i * MAXC + i];
+                      }
+                      for (int i = m - 1; i >= 0; --i) {
+                        double s2 = mult[i];
+                        for (int q = i + 1; q < m; ++q) s2 -= Sc[q * MAXC + i] * mult[q];
+                        mult[i] = s2 / Sc[i * MAXC + i];
+                      }
+                    } else {
+                      for (int i = 0; i < m; ++i) mult[i] = 0.;
+                    }
+                    flag[0] = okc ? 1. : 0.;
+                  }
+                  wsync();
+                  ok_a = flag[0] != 0.;
                 }
-                flag[0] = okc ? 1. : 0.;
               }
-              wsync();
-              ok_step = flag[0] != 0.;
             }
-          }
-        }
-        STAMP(4);
-        if (!converged) {
-          if (!ok_step) {
-            mu *= nu; nu *= 2.; last_acc = false;
-            if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
-            next = BP_STEP_ONLY;
-          } else {
+            if (!ok_a) continue;
             if (!have_dl) {
               for (int i = lane; i < nv; i += WAVE) dl[i] = 0.;
               wsync();
@@ -888,7 +1031,8 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
               }
               wsync();
             }
-            double stepmax = 0.;
+            // projected trial point
+            stepmax = 0.;
             for (int i = lane; i < nv; i += WAVE) {
               double t = v[i] + dl[i];
               t = t < lo[i] ? lo[i] : (t > hi[i] ? hi[i] : t);
@@ -903,26 +1047,44 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             for (int i = lane; i < nv; i += WAVE) {
               double t = 0.;
               for (int j = 0; j < nv; ++j) t += Msym(Mp, i + 1, j + 1) * dl[j];
+              if (nwt && vfeat[i] >= 0) {
+                const int j0 = L.nshared + vfeat[i] * L.npf;
+                for (int j = j0; j < j0 + L.npf; ++j) t += qvar(i, j) * dl[j];
+                if (m)
+                  for (int j = L.nshared; j < nv; ++j) t += ccurv(i, j) * dl[j];
+              }
               partial += dl[i] * (Mp[tri(i + 1)] + 0.5 * t);
             }
             pred = -wave_sum(partial);
-            cn = 0.;
             if (m) {
               double cn_lin = 0., mmax = 0.;
               for (int r = 0; r < m; ++r) {
                 double t = cv[r];
                 for (int i = 0; i < nv; ++i) t += Cj[r * LDC + i] * dl[i];
-                cn += fabs(cv[r]);
                 cn_lin += fabs(t);
                 mmax = fmax(mmax, fabs(mult[r]));
               }
-              if (sigma < 2. * mmax) sigma = 2. * mmax;
-              pred += sigma * (cn - cn_lin);
+              // penalty weight of the l1 merit function, Powell's rule (as SLSQP's line search)
+              sigma_t = 0.5 * (sigma + mmax);
+              if (sigma_t < mmax) sigma_t = mmax;
+              pred += sigma_t * (cn - cn_lin);
+              cn_pred = cn_lin;
             }
             pred = bcast0(pred);
             stepmax = bcast0(stepmax);
+            if (nwt && !(pred > -tiny)) continue;
+            ok_step = true;
+          }
+          sigma = bcast0(sigma_t);
+          cn_pred = bcast0(cn_pred);
+          STAMP(4);
+          if (!ok_step) {
+            mu *= nu; nu *= 2.; last_acc = false;
+            if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+            next = BP_STEP_ONLY;
+          } else {
             const bool feasible = (m == 0) || (cn <= 1e-10);
-            converged = feasible && ((last_acc && stepmax <= xtol) || pred <= ftol * (0.5 * S) + 1e-300);
+            converged = feasible && ((last_acc && stepmax <= xtol) || fabs(pred) <= tiny);
             next = BP_EVAL_TRIAL;
           }
         }

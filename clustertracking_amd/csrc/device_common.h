@@ -12,6 +12,9 @@ constexpr int MAXC = 6;       // equality constraints per cluster
 constexpr int MAXF = 64;      // features per cluster
 constexpr int MAXNT = 8;      // 16*8 = 128 columns >= CTR_MAX_VARS + 1
 constexpr int FP = 14;        // derived per-feature constants (see fill_fpar)
+// at the iteration limit a fit whose last accepted step lowered the objective by less than this
+// (relative) is reported as converged; same rule as STALL_TOL in oracle/ctr_oracle.c
+#define CTR_STALL_TOL 1e-9
 
 struct KArgs {
   ctr_problem prob;
@@ -61,6 +64,38 @@ __device__ __forceinline__ double wave_max(double x) {
   return x;
 }
 __device__ __forceinline__ double bcast0(double x) { return __shfl(x, 0); }
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+  const long long b = __double_as_longlong(x);
+  int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// all-reduce inside each 16-lane DPP row
+__device__ __forceinline__ double row_sum(double x) {
+  x += dpp_f64<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += dpp_f64<0x4E>(x);   // quad_perm [2,3,0,1]
+  x += dpp_f64<0x141>(x);  // row_half_mirror
+  x += dpp_f64<0x140>(x);  // row_mirror
+  return x;
+}
+// Four wave-wide sums for the price of one and a half: after two exchange steps every
+// 16-lane row carries one of the four values, which the DPP row reduction finishes.
+// Returns, in every lane of row r (lanes 16r..16r+15), the sum over the wave of v_r.
+__device__ __forceinline__ double wave_sum4(double v0, double v1, double v2, double v3, int lane) {
+  const bool up = (lane & 32) != 0;
+  double ka = up ? v2 : v0, kb = up ? v3 : v1;
+  const double sa = up ? v0 : v2, sb = up ? v1 : v3;
+  ka += __shfl_xor(sa, 32);
+  kb += __shfl_xor(sb, 32);
+  const bool hi = (lane & 16) != 0;
+  double kk = hi ? kb : ka;
+  const double ss = hi ? ka : kb;
+  kk += __shfl_xor(ss, 16);
+  return row_sum(kk);
+}
 
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
 

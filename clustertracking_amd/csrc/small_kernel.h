@@ -18,22 +18,6 @@
 // Variable order (fitfunc.py:207-263): [bg, s_0.., pos(axis 0)_0.., pos(axis 1)_0.., ...].
 
 
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double x) {
-  const long long b = __double_as_longlong(x);
-  int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-// all-reduce inside each 16-lane DPP row
-__device__ __forceinline__ double row_sum(double x) {
-  x += dpp_f64<0xB1>(x);   // quad_perm [1,0,3,2]
-  x += dpp_f64<0x4E>(x);   // quad_perm [2,3,0,1]
-  x += dpp_f64<0x141>(x);  // row_half_mirror
-  x += dpp_f64<0x140>(x);  // row_mirror
-  return x;
-}
 // all-reduce inside a group of SG lanes (16 = one DPP row, 64 = the whole wave)
 template <int SG>
 __device__ __forceinline__ double group_sum(double x) {
@@ -54,13 +38,16 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
   constexpr int NV = 1 + NF * (1 + ND);
   constexpr int NR = NV + 1;               // row length incl. the residual
   constexpr int NM = NR * (NR + 1) / 2;    // packed upper triangle
+  constexpr int NUF = ND * (ND + 1) / 2;   // second-order sums per feature: U[a<=b] = sum res J_pos_a dE/dpos_b
+  constexpr int NU = NF * NUF;
+  constexpr int NA = NM + NU;              // everything a pass over the window accumulates
   constexpr int NP = 2 + ND + (ISO ? 1 : ND);
   const int lane = threadIdx.x, sub = lane & (SG - 1), grp = lane / SG;
-  // per group: Mcur[NM] v0[NV] lo[NV] hi[NV]
-  constexpr int GS = NM + 3 * NV;
+  // per group: Mcur[NM] Ucur[NU] v0[NV] lo[NV] hi[NV]
+  constexpr int GS = NA + 3 * NV;
   __shared__ double lds[(WAVE / SG) * GS];
   double* Mcur = lds + grp * GS;
-  double* v0 = Mcur + NM;
+  double* v0 = Mcur + NA;
   double* lo = v0 + NV;
   double* hi = lo + NV;
 
@@ -87,6 +74,7 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
   double mco[NF][ND], isz2[NF][ND];  // mask centres, 1/size^2 (p0 rows are re-read from HBM when needed)
   double mu = 1e-3, nu = 2., S = 0., pred = 0., norm = 1., rms = NAN;
   bool last_acc = true;
+  double gain = INFINITY;  // relative decrease of S by the last accepted step
   const char* frame = nullptr;
 
   while (true) {
@@ -198,9 +186,9 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
     if (__all(phase == PH_DONE)) break;
 
     // ---- 2. one pass over the window at vt: M = [J r]^T [J r], P ----------------
-    double M[NM];
+    double M[NA];
 #pragma unroll
-    for (int e = 0; e < NM; ++e) M[e] = 0.;
+    for (int e = 0; e < NA; ++e) M[e] = 0.;
     int P = 0;
     const bool evaluating = (phase == PH_EVAL_INIT || phase == PH_EVAL_TRIAL);
     const int npix_here = evaluating ? npix : 0;
@@ -235,6 +223,11 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
           for (int j = 0; j < NR; ++j) row[j] = 0.;
           bool any = false;
           double res = 0.;
+          double Ed[NF][ND];  // d(-ND/2 r2)/d pos of the features covering this pixel, else 0
+#pragma unroll
+          for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int a = 0; a < ND; ++a) Ed[i][a] = 0.;
 #pragma unroll
           for (int i = 0; i < NF; ++i) {
             double rel[ND];
@@ -254,7 +247,11 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
               row[1 + i] = -gv;
               const double sng = -sig * (double)ND * gv;
 #pragma unroll
-              for (int a = 0; a < ND; ++a) row[1 + NF + a * NF + i] = sng * dd[a] * isz2[i][a];
+              for (int a = 0; a < ND; ++a) {
+                const double t = dd[a] * isz2[i][a];
+                row[1 + NF + a * NF + i] = sng * t;
+                Ed[i][a] = (double)ND * t;
+              }
             }
           }
           if (any) {
@@ -268,6 +265,15 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
               for (int p = 0; p < NR; ++p)
 #pragma unroll
                 for (int c2 = p; c2 < NR; ++c2) { M[e] += row[p] * row[c2]; ++e; }
+              // second-order sums (block_kernel.h / oracle solve(): the exact model Hessian)
+#pragma unroll
+              for (int i = 0; i < NF; ++i)
+#pragma unroll
+                for (int a = 0; a < ND; ++a) {
+                  const double rj = res * row[1 + NF + a * NF + i];
+#pragma unroll
+                  for (int b = a; b < ND; ++b) { M[e] += rj * Ed[i][b]; ++e; }
+                }
             }
           }
         }
@@ -275,7 +281,7 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
     }
     if (__any(evaluating)) {
 #pragma unroll
-      for (int e = 0; e < NM; ++e) M[e] = group_sum<SG>(M[e]);
+      for (int e = 0; e < NA; ++e) M[e] = group_sum<SG>(M[e]);
       P = (int)group_sum<SG>((double)P);
     }
 
@@ -286,7 +292,7 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
       if (phase == PH_EVAL_INIT) {
         if (P == 0) { status = CTR_STATUS_OUT_OF_BOUNDS; failed = true; }
         else if (!isfinite(St)) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
-        mu = 1e-3; nu = 2.; last_acc = true;
+        mu = 1e-3; nu = 2.; last_acc = true; gain = INFINITY;
         Pround = P;
       }
       bool accept = phase == PH_EVAL_INIT;
@@ -297,6 +303,7 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
           const double f = 1. - t * t * t;
           mu *= f > 1. / 3. ? f : 1. / 3.;
           nu = 2.;
+          gain = act / (0.5 * S + 1e-300);
           accept = true;
           last_acc = true;
         } else {
@@ -310,14 +317,18 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
         S = St;
         if (sub == 0) {
 #pragma unroll
-          for (int e = 0; e < NM; ++e) Mcur[e] = M[e];
+          for (int e = 0; e < NA; ++e) Mcur[e] = M[e];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
-      if (!failed && it >= maxiter) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
       bool converged = false;
-      if (!failed) {
+      if (!failed && it >= maxiter) {
+        // iteration limit: a stationary objective still counts as converged (see solve() of the oracle)
+        if (gain <= CTR_STALL_TOL) converged = true;
+        else { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+      }
+      if (!failed && !converged) {
         ++it;
         ++iters;
         // Mcur: upper triangle packed row-major over [J r]; g = last column
@@ -340,73 +351,122 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
         if (nfree == 0) {
           converged = true;
         } else {
-          double L[NV][NV], rhs[NV], dinv[NV];
-          bool okc = true;
+          // model Hessians (lower triangles): GN = J^T J; NW adds sum_p res_p d2res_p over
+          // (signal, positions) of each feature -- U from the pixel pass, the rest from the
+          // gradient: d2res/ds dpos_a = g_pos_a / s,  d2res/dpos_a^2 += (-ND/size_a^2) s g_s
+          double Hn[NV][NV];
 #pragma unroll
-          for (int p = 0; p < NV; ++p) {
+          for (int p = 0; p < NV; ++p)
 #pragma unroll
-            for (int c2 = 0; c2 <= p; ++c2) {
-              double h = (fixed[p] || fixed[c2]) ? 0. : Mc(p, c2);
-              if (p == c2) h = fixed[p] ? 1. : h + mu * (h > 1e-300 ? h : 1.);
-              L[p][c2] = h;
-            }
-            rhs[p] = fixed[p] ? 0. : g[p];
-          }
+            for (int c2 = 0; c2 <= p; ++c2) Hn[p][c2] = Mc(p, c2);
 #pragma unroll
-          for (int j = 0; j < NV; ++j) {
-            double d = L[j][j];
+          for (int i = 0; i < NF; ++i) {
+            const double sig = v[1 + i], gs = g[1 + i];
 #pragma unroll
-            for (int q2 = 0; q2 < j; ++q2) d -= L[j][q2] * L[j][q2];
-            if (!(d > 0.) || !isfinite(d)) okc = false;
-            const double di = 1. / sqrt(d);
-            dinv[j] = di;
+            for (int a = 0; a < ND; ++a) {
+              const int ca = 1 + NF + a * NF + i;
+              Hn[ca][1 + i] += sig != 0. ? g[ca] / sig : 0.;
 #pragma unroll
-            for (int i = j + 1; i < NV; ++i) {
-              double s = L[i][j];
-#pragma unroll
-              for (int q2 = 0; q2 < j; ++q2) s -= L[i][q2] * L[j][q2];
-              L[i][j] = s * di;
+              for (int b = 0; b <= a; ++b) {
+                double u = Mcur[NM + i * NUF + (b * ND - (b * (b - 1)) / 2 + (a - b))];
+                if (a == b) u -= (double)ND * isz2[i][a] * sig * gs;
+                Hn[ca][1 + NF + b * NF + i] += u;
+              }
             }
           }
-          if (!okc) {
-            mu *= nu; nu *= 2.; last_acc = false;
-            if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
-            phase = PH_STEP_ONLY;
-          } else {
+          // one LM step on the free variables with model `newton ? Hn : GN`; false = not positive definite
+          auto lm_step = [&](bool newton, double (&vnew)[NV], double& smax, double& pr) -> bool {
+            double L[NV][NV], rhs[NV], dinv[NV];
+            bool okc = true;
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+#pragma unroll
+              for (int c2 = 0; c2 <= p; ++c2) {
+                double h = (fixed[p] || fixed[c2]) ? 0. : (newton ? Hn[p][c2] : Mc(p, c2));
+                if (p == c2) {
+                  const double d = Mc(p, p);
+                  h = fixed[p] ? 1. : h + mu * (d > 1e-300 ? d : 1.);
+                }
+                L[p][c2] = h;
+              }
+              rhs[p] = fixed[p] ? 0. : g[p];
+            }
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+              double d = L[j][j];
+#pragma unroll
+              for (int q2 = 0; q2 < j; ++q2) d -= L[j][q2] * L[j][q2];
+              if (!(d > 0.) || !isfinite(d)) okc = false;
+              const double di = 1. / sqrt(d);
+              dinv[j] = di;
+#pragma unroll
+              for (int i = j + 1; i < NV; ++i) {
+                double t = L[i][j];
+#pragma unroll
+                for (int q2 = 0; q2 < j; ++q2) t -= L[i][q2] * L[j][q2];
+                L[i][j] = t * di;
+              }
+            }
+            if (!okc) return false;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-              double s = rhs[i];
+              double t = rhs[i];
 #pragma unroll
-              for (int q2 = 0; q2 < i; ++q2) s -= L[i][q2] * rhs[q2];
-              rhs[i] = s * dinv[i];
+              for (int q2 = 0; q2 < i; ++q2) t -= L[i][q2] * rhs[q2];
+              rhs[i] = t * dinv[i];
             }
 #pragma unroll
             for (int i = NV - 1; i >= 0; --i) {
-              double s = rhs[i];
+              double t = rhs[i];
 #pragma unroll
-              for (int q2 = i + 1; q2 < NV; ++q2) s -= L[q2][i] * rhs[q2];
-              rhs[i] = s * dinv[i];
+              for (int q2 = i + 1; q2 < NV; ++q2) t -= L[q2][i] * rhs[q2];
+              rhs[i] = t * dinv[i];
             }
-            double dl[NV], stepmax = 0.;
+            double dl[NV];
+            smax = 0.;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
               double t = v[j] - rhs[j];
               const double l = lo[j], h = hi[j];
               t = t < l ? l : (t > h ? h : t);
-              vt[j] = t;
+              vnew[j] = t;
               dl[j] = t - v[j];
-              stepmax = fmax(stepmax, fabs(dl[j]) / (fabs(v[j]) + 1.));
+              smax = fmax(smax, fabs(dl[j]) / (fabs(v[j]) + 1.));
             }
             double acc = 0.;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
               double t = 0.;
 #pragma unroll
-              for (int j = 0; j < NV; ++j) t += Mc(i, j) * dl[j];
+              for (int j = 0; j < NV; ++j) {
+                const int hi_ = i > j ? i : j, lo_ = i > j ? j : i;
+                t += (newton ? Hn[hi_][lo_] : Mc(hi_, lo_)) * dl[j];
+              }
               acc += dl[i] * (g[i] + 0.5 * t);
             }
-            pred = -acc;
-            converged = (last_acc && stepmax <= xtol) || pred <= ftol * (0.5 * S) + 1e-300;
+            pr = -acc;
+            return true;
+          };
+          const double tiny = ftol * (0.5 * S) + 1e-300;
+          double stepmax = 0.;
+          // the exact Hessian first; Gauss-Newton where that is not positive definite on the
+          // free variables or its projected step is not a descent step of the model
+          bool ok_step = lm_step(true, vt, stepmax, pred) && pred > -tiny;
+          if (__any(!ok_step)) {
+            double vg[NV], sg = 0., pg = 0.;
+            const bool okg = lm_step(false, vg, sg, pg);
+            if (!ok_step && okg) {
+#pragma unroll
+              for (int j = 0; j < NV; ++j) vt[j] = vg[j];
+              stepmax = sg; pred = pg; ok_step = true;
+            }
+          }
+          if (!ok_step) {
+            mu *= nu; nu *= 2.; last_acc = false;
+            if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+            phase = PH_STEP_ONLY;
+          } else {
+            converged = (last_acc && stepmax <= xtol) || fabs(pred) <= tiny;
             phase = PH_EVAL_TRIAL;
           }
         }

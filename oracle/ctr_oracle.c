@@ -192,7 +192,7 @@ static int n_constraints(const ctr_problem* p, int n) {
 }
 
 /* c[m] and Jacobian Cj[m][nv] at v */
-static void eval_constraints(const ctx_t* c, const double* v, double* cv, double* Cj) {
+static void eval_constraints(const ctx_t* c, const double* v, double* cv, double* Cj, int* pair_of) {
   const int nd = c->L.nd, nv = c->L.nv, m = c->n_cons;
   int npairs = c->p->constraint_kind == CTR_CONS_DIMER ? 1
              : c->p->constraint_kind == CTR_CONS_TRIMER ? 3 : 6;
@@ -221,6 +221,7 @@ static void eval_constraints(const ctx_t* c, const double* v, double* cv, double
   for (int r = 0; r < m; ++r) {
     int q = order[r];
     int i0 = PAIRS[q][0], i1 = PAIRS[q][1];
+    if (pair_of) pair_of[r] = q;
     cv[r] = 1. - d2[q];
     for (int a = 0; a < nd; ++a) {
       int k = 2 + a, b = c->L.var_of[k];
@@ -236,7 +237,7 @@ static void eval_constraints(const ctx_t* c, const double* v, double* cv, double
 /* ---- objective: S = sum r^2, g = J^T r, A = J^T J ------------------------- */
 
 static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double* g,
-                         double* A, long* P_out) {
+                         double* A, double* Q, long* P_out) {
   const layout_t* L = &c->L;
   const int nd = L->nd, nv = L->nv, n = L->n, np = L->np;
   const int64_t* fshape = c->b->shape;
@@ -251,13 +252,18 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
   const int w0 = nd == 3 ? c->wshape[0] : 1, w1 = c->wshape[nd - 2], w2 = c->wshape[nd - 1];
   if (g) memset(g, 0, sizeof(double) * nv);
   if (A) memset(A, 0, sizeof(double) * nv * nv);
+  if (Q) memset(Q, 0, sizeof(double) * nv * nv);
+  /* second-order part (see solve()): U[i][a][b] = sum_p res * J_pos_a * dE/dpos_b of feature i */
+  double U[MAXV][3][3];
+  struct { int i; double J[3], E[3]; } hf[MAXV];
+  if (Q) memset(U, 0, sizeof(double) * (size_t)n * 9);
   for (int z = 0; z < w0; ++z)
     for (int y = 0; y < w1; ++y)
       for (int x = 0; x < w2; ++x) {
         int idx[3];
         double mesh[3];
         size_t off;
-        int any = 0, nnz = 0;
+        int any = 0, nnz = 0, nhf = 0;
         double res = 0.;
         if (nd == 3) {
           idx[0] = z; idx[1] = y; idx[2] = x;
@@ -298,6 +304,14 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
           const double gv = exp(-0.5 * nd * r2); /* fitfunc.py:112-118 */
           const double dg = -0.5 * nd * gv;
           res -= sig * gv;
+          if (Q) {
+            hf[nhf].i = i;
+            for (int a = 0; a < nd; ++a) {
+              hf[nhf].J[a] = -sig * dg * dr2[a];       /* d res / d pos_a */
+              hf[nhf].E[a] = -0.5 * nd * dr2[a];       /* d (-nd/2 r2) / d pos_a */
+            }
+            ++nhf;
+          }
           if (g) {
             /* d res / d signal, positions, sizes (fitfunc.py:475-478, sign of the residual) */
             double d[1 + 6];
@@ -326,7 +340,33 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
             for (int t = 0; t < nnz; ++t) A[cs * nv + nz[t]] += rs * row[nz[t]];
           }
         }
+        if (Q)
+          for (int f = 0; f < nhf; ++f)
+            for (int a = 0; a < nd; ++a)
+              for (int b2 = a; b2 < nd; ++b2) U[hf[f].i][a][b2] += res * hf[f].J[a] * hf[f].E[b2];
       }
+  if (Q) {
+    /* sum_p res_p d2res_p/dv dv restricted to (signal, positions) of each feature; all but U
+     * follows from the gradient:  d2res/ds dpos_a = (dres/dpos_a)/s,
+     * d2res/dpos_a dpos_b = J_a E_b + delta_ab (-nd/size_a^2) s (dres/ds) */
+    memset(Q, 0, sizeof(double) * nv * nv);
+    for (int i = 0; i < n; ++i) {
+      const int cs = L->var_of[1] + i;
+      const double sig = v[cs];
+      for (int a = 0; a < nd; ++a) {
+        const int ca = L->var_of[2 + a] + i;
+        const double sz = par(c, v, i, c->p->isotropic ? 2 + nd : 2 + nd + a);
+        const double t = sig != 0. ? g[ca] / sig : 0.;
+        Q[cs * nv + ca] = Q[ca * nv + cs] = t;
+        for (int b2 = a; b2 < nd; ++b2) {
+          const int cb = L->var_of[2 + b2] + i;
+          double u = U[i][a][b2];
+          if (a == b2) u += -(double)nd / (sz * sz) * sig * g[cs];
+          Q[ca * nv + cb] = Q[cb * nv + ca] = u;
+        }
+      }
+    }
+  }
   *S_out = S;
   *P_out = P;
 }
@@ -365,6 +405,11 @@ static void chol_solve(const double* Lm, int n, int ld, double* x) {
 
 /* ---- bounded (+ equality constrained) Levenberg-Marquardt ----------------- */
 
+#define STALL_TOL 1e-9
+/* diagnostic switch: 0 = Gauss-Newton model only (for A/B measurements of the oracle itself) */
+static int use_newton = 1;
+void ctro_set_newton(int on) { use_newton = on; }
+
 typedef struct { double S; long P; int iters; int ok; } solve_t;
 
 static double l1norm(const double* c, int m) {
@@ -382,28 +427,36 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
   solve_t out = {NAN, 0, 0, 0};
   double *g = malloc(sizeof(double) * nv), *A = malloc(sizeof(double) * nv * nv);
   double *gt = malloc(sizeof(double) * nv), *At = malloc(sizeof(double) * nv * nv);
+  double *Q = calloc((size_t)nv * nv, sizeof(double)), *Qt = calloc((size_t)nv * nv, sizeof(double));
+  double *B = malloc(sizeof(double) * nv * nv); /* model Hessian: A + Q + sum mult d2c */
+  int pair_of[MAXC], pair_of_t[MAXC];
+  /* exact second-order terms are used when signal and positions are per-feature variables
+   * (the default modes); otherwise the model Hessian is J^T J throughout */
+  int newton = use_newton && c->p->modes[1] == CTR_MODE_VAR;
+  for (int a = 0; a < c->L.nd; ++a) newton = newton && c->p->modes[2 + a] == CTR_MODE_VAR;
   double *H = malloc(sizeof(double) * nv * nv), *vt = malloc(sizeof(double) * nv);
   double *dl = malloc(sizeof(double) * nv), *w = malloc(sizeof(double) * nv);
   double *Y = malloc(sizeof(double) * nv * MAXC), *Cj = malloc(sizeof(double) * nv * MAXC);
   double *Cjt = malloc(sizeof(double) * nv * MAXC);
   int* fr = malloc(sizeof(int) * nv);
   double cv[MAXC], cvt[MAXC], mult[MAXC], Sc[MAXC * MAXC];
-  double S, St, mu, nu = 2., sigma = 0.;
+  double S, St, mu, nu = 2., sigma = 0., tau = 1.;
   long P;
-  int last_accepted = 1;
+  int last_accepted = 1, it;
+  double gain = INFINITY; /* relative merit decrease of the last accepted step */
 
   for (int i = 0; i < nv; ++i) {
     if (lo[i] > hi[i]) goto done; /* infeasible box (SciPy raises ValueError) */
     v[i] = v0[i] < lo[i] ? lo[i] : (v0[i] > hi[i] ? hi[i] : v0[i]);
   }
-  eval_cluster(c, v, &S, g, A, &P);
+  eval_cluster(c, v, &S, g, A, newton ? Q : NULL, &P);
   out.P = P;
   if (P == 0 || !isfinite(S)) goto done;
-  eval_constraints(c, v, cv, Cj);
+  eval_constraints(c, v, cv, Cj, pair_of);
   memset(mult, 0, sizeof mult);
   mu = 1e-3; /* multiplies the Marquardt diagonal below */
 
-  for (int it = 0; it < maxiter; ++it) {
+  for (it = 0; it < maxiter; ++it) {
     int nf = 0;
     out.iters = it + 1;
     /* active set: fixed if at a bound and the Lagrangian gradient pushes outward */
@@ -414,93 +467,135 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
       if (!fixed) fr[nf++] = i;
     }
     if (nf == 0) { out.ok = 1; break; }
-    for (int a = 0; a < nf; ++a) {
-      for (int b = 0; b <= a; ++b) H[a * nf + b] = A[fr[a] * nv + fr[b]];
-      double d = A[fr[a] * nv + fr[a]];
-      H[a * nf + a] += mu * (d > 1e-300 ? d : 1.);
-    }
-    if (!cholesky(H, nf, nf)) { mu *= nu; nu *= 2.; last_accepted = 0; if (mu > 1e30) break; continue; }
-    for (int a = 0; a < nf; ++a) w[a] = g[fr[a]];
-    chol_solve(H, nf, nf, w); /* w = H^-1 g_F */
-    memset(dl, 0, sizeof(double) * nv);
-    if (m == 0) {
-      for (int a = 0; a < nf; ++a) dl[fr[a]] = -w[a];
-    } else {
-      /* range-space step: (C H^-1 C^T) mult = c - C H^-1 g ; d = -H^-1 (g + C^T mult) */
-      for (int r = 0; r < m; ++r) {
-        for (int a = 0; a < nf; ++a) Y[r * nf + a] = Cj[r * nv + fr[a]];
-        chol_solve(H, nf, nf, Y + r * nf);
-      }
-      for (int r = 0; r < m; ++r) {
-        for (int s = 0; s <= r; ++s) {
-          double t = 0.;
-          for (int a = 0; a < nf; ++a) t += Cj[r * nv + fr[a]] * Y[s * nf + a];
-          Sc[r * m + s] = t;
+    /* Model Hessian.  First choice: the exact one, J^T J + sum_p r_p d2r_p + sum_r mult_r d2c_r
+     * (quadratic convergence also where the residual stays large: overlapping features,
+     * constrained fits).  Where that is not positive definite on the free variables, or its
+     * projected step is not a descent step of the model, the Gauss-Newton matrix J^T J is
+     * used for this iteration instead. */
+    double stepmax = 0., pred = 0., cn = l1norm(cv, m), sigma_t = sigma, cn_pred = 0.;
+    double mult0[MAXC];
+    int step_ok = 0;
+    memcpy(mult0, mult, sizeof mult0);
+    for (int attempt = newton ? 1 : 0; attempt >= 0 && !step_ok; --attempt) {
+      memcpy(B, A, sizeof(double) * nv * nv);
+      if (attempt == 1) {
+        for (int i = 0; i < nv * nv; ++i) B[i] += Q[i];
+        /* curvature of the constraints (c_r = 1 - |dp/dist|^2), multipliers of the last step */
+        for (int r = 0; r < m; ++r) {
+          int i0 = PAIRS[pair_of[r]][0], i1 = PAIRS[pair_of[r]][1];
+          for (int a = 0; a < c->L.nd; ++a) {
+            int k = 2 + a, b = c->L.var_of[k];
+            if (b < 0 || !c->L.per_feat[k]) continue;
+            double da = c->p->constraint_dist[a], t = -2. * mult0[r] / (da * da);
+            B[(b + i0) * nv + b + i0] += t;
+            B[(b + i1) * nv + b + i1] += t;
+            B[(b + i0) * nv + b + i1] -= t;
+            B[(b + i1) * nv + b + i0] -= t;
+          }
         }
-        double t = cv[r];
-        for (int a = 0; a < nf; ++a) t -= Cj[r * nv + fr[a]] * w[a];
-        mult[r] = t;
       }
-      {
-        double tr = 0.;
-        for (int r = 0; r < m; ++r) tr += Sc[r * m + r];
-        for (int r = 0; r < m; ++r) Sc[r * m + r] += 1e-14 * tr + 1e-300;
-      }
-      if (!cholesky(Sc, m, m)) { mu *= nu; nu *= 2.; last_accepted = 0; memset(mult, 0, sizeof mult); if (mu > 1e30) break; continue; }
-      chol_solve(Sc, m, m, mult);
       for (int a = 0; a < nf; ++a) {
-        double t = w[a];
-        for (int r = 0; r < m; ++r) t += Y[r * nf + a] * mult[r];
-        dl[fr[a]] = -t;
+        for (int b = 0; b <= a; ++b) H[a * nf + b] = B[fr[a] * nv + fr[b]];
+        double d = A[fr[a] * nv + fr[a]];
+        H[a * nf + a] += mu * (d > 1e-300 ? d : 1.);
       }
-    }
-    /* projected trial point */
-    double stepmax = 0., gd = 0., dAd = 0.;
-    for (int i = 0; i < nv; ++i) {
-      double t = v[i] + dl[i];
-      t = t < lo[i] ? lo[i] : (t > hi[i] ? hi[i] : t);
-      vt[i] = t;
-      dl[i] = t - v[i];
-      double rel = fabs(dl[i]) / (fabs(v[i]) + 1.);
-      if (rel > stepmax) stepmax = rel;
-    }
-    for (int i = 0; i < nv; ++i) {
-      double t = 0.;
-      for (int j = 0; j < nv; ++j) t += A[i * nv + j] * dl[j];
-      dAd += dl[i] * t;
-      gd += g[i] * dl[i];
-    }
-    double pred = -(gd + 0.5 * dAd);
-    double cn = l1norm(cv, m), cn_lin = 0.;
-    if (m) {
-      double mmax = 0.;
-      for (int r = 0; r < m; ++r) {
-        double t = cv[r];
-        for (int i = 0; i < nv; ++i) t += Cj[r * nv + i] * dl[i];
-        cn_lin += fabs(t);
-        if (fabs(mult[r]) > mmax) mmax = fabs(mult[r]);
+      if (!cholesky(H, nf, nf)) continue;
+      for (int a = 0; a < nf; ++a) w[a] = g[fr[a]];
+      chol_solve(H, nf, nf, w); /* w = H^-1 g_F */
+      memset(dl, 0, sizeof(double) * nv);
+      if (m == 0) {
+        for (int a = 0; a < nf; ++a) dl[fr[a]] = -w[a];
+      } else {
+        /* range-space step: (C H^-1 C^T) mult = c - C H^-1 g ; d = -H^-1 (g + C^T mult) */
+        for (int r = 0; r < m; ++r) {
+          for (int a = 0; a < nf; ++a) Y[r * nf + a] = Cj[r * nv + fr[a]];
+          chol_solve(H, nf, nf, Y + r * nf);
+        }
+        for (int r = 0; r < m; ++r) {
+          for (int s = 0; s <= r; ++s) {
+            double t = 0.;
+            for (int a = 0; a < nf; ++a) t += Cj[r * nv + fr[a]] * Y[s * nf + a];
+            Sc[r * m + s] = t;
+          }
+          double t = tau * cv[r]; /* damped normal step: C d = -tau c */
+          for (int a = 0; a < nf; ++a) t -= Cj[r * nv + fr[a]] * w[a];
+          mult[r] = t;
+        }
+        {
+          double tr = 0.;
+          for (int r = 0; r < m; ++r) tr += Sc[r * m + r];
+          for (int r = 0; r < m; ++r) Sc[r * m + r] += 1e-14 * tr + 1e-300;
+        }
+        if (!cholesky(Sc, m, m)) { memset(mult, 0, sizeof mult); continue; }
+        chol_solve(Sc, m, m, mult);
+        for (int a = 0; a < nf; ++a) {
+          double t = w[a];
+          for (int r = 0; r < m; ++r) t += Y[r * nf + a] * mult[r];
+          dl[fr[a]] = -t;
+        }
       }
-      if (sigma < 2. * mmax) sigma = 2. * mmax;
-      pred += sigma * (cn - cn_lin);
+      /* projected trial point */
+      double gd = 0., dAd = 0.;
+      stepmax = 0.;
+      for (int i = 0; i < nv; ++i) {
+        double t = v[i] + dl[i];
+        t = t < lo[i] ? lo[i] : (t > hi[i] ? hi[i] : t);
+        vt[i] = t;
+        dl[i] = t - v[i];
+        double rel = fabs(dl[i]) / (fabs(v[i]) + 1.);
+        if (rel > stepmax) stepmax = rel;
+      }
+      for (int i = 0; i < nv; ++i) {
+        double t = 0.;
+        for (int j = 0; j < nv; ++j) t += B[i * nv + j] * dl[j];
+        dAd += dl[i] * t;
+        gd += g[i] * dl[i];
+      }
+      pred = -(gd + 0.5 * dAd);
+      if (m) {
+        double mmax = 0., cn_lin = 0.;
+        for (int r = 0; r < m; ++r) {
+          double t = cv[r];
+          for (int i = 0; i < nv; ++i) t += Cj[r * nv + i] * dl[i];
+          cn_lin += fabs(t);
+          if (fabs(mult[r]) > mmax) mmax = fabs(mult[r]);
+        }
+        /* penalty weight of the l1 merit function, Powell's rule (as SLSQP's line search) */
+        sigma_t = 0.5 * (sigma + mmax);
+        if (sigma_t < mmax) sigma_t = mmax;
+        pred += sigma_t * (cn - cn_lin);
+        cn_pred = cn_lin;
+      }
+      if (attempt == 1 && !(pred > -(ftol * (0.5 * S) + 1e-300))) continue;
+      step_ok = 1;
     }
-    /* converged: negligible step after an accepted one, or negligible model decrease */
-    if (getenv("CTRO_TRACE")) fprintf(stderr, "it %d S %.12e mu %.3e step %.3e pred %.3e nf %d\n", it, S, mu, stepmax, pred, nf);
+    sigma = sigma_t;
+    if (!step_ok) { mu *= nu; nu *= 2.; last_accepted = 0; if (mu > 1e30) break; continue; }
+    /* converged: negligible step after an accepted one, or negligible model change.
+     * A clearly NEGATIVE predicted decrease (the projection onto the box turned the
+     * step uphill) is not convergence: the trial below is then rejected and mu grows,
+     * which turns the step towards the projected gradient. */
     int feasible = (m == 0) || (cn <= 1e-10);
-    if (feasible && ((last_accepted && stepmax <= xtol) || pred <= ftol * (0.5 * S) + 1e-300)) {
+    if (feasible && ((last_accepted && stepmax <= xtol) || fabs(pred) <= ftol * (0.5 * S) + 1e-300)) {
       out.ok = 1;
       break;
     }
-    eval_cluster(c, vt, &St, gt, At, &P);
-    eval_constraints(c, vt, cvt, Cjt);
-    double act = 0.5 * (S - St) + (m ? sigma * (cn - l1norm(cvt, m)) : 0.);
+    eval_cluster(c, vt, &St, gt, At, newton ? Qt : NULL, &P);
+    eval_constraints(c, vt, cvt, Cjt, pair_of_t);
+    const double cnt = l1norm(cvt, m);
+    double act = 0.5 * (S - St) + (m ? sigma * (cn - cnt) : 0.);
     if (isfinite(St) && pred > 0. && act > 0.) {
       double rho = act / pred, t = 2. * rho - 1.;
       double f = 1. - t * t * t;
       mu *= f > 1. / 3. ? f : 1. / 3.;
       nu = 2.;
+      gain = act / (0.5 * S + 1e-300);
+      tau = tau < 0.5 ? 2. * tau : 1.;
       memcpy(v, vt, sizeof(double) * nv);
       memcpy(g, gt, sizeof(double) * nv);
       memcpy(A, At, sizeof(double) * nv * nv);
+      memcpy(Q, Qt, sizeof(double) * nv * nv);
+      memcpy(pair_of, pair_of_t, sizeof pair_of);
       memcpy(cv, cvt, sizeof(double) * (m ? m : 1));
       memcpy(Cj, Cjt, sizeof(double) * (size_t)(m ? m : 0) * nv);
       S = St;
@@ -508,14 +603,21 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
     } else {
       mu *= nu;
       nu *= 2.;
+      /* the linearised constraints promised more than half of what the trial delivered:
+       * shorten the normal step as well */
+      if (m && cnt > cn_pred + 0.5 * (cn - cn_pred)) tau *= 0.5;
       last_accepted = 0;
       if (mu > 1e30) break;
     }
   }
+  /* iteration limit with a stationary objective: the last accepted step lowered it by
+   * less than STALL_TOL (relative).  The reference's SLSQP stops at |dF| < 1e-6 absolute
+   * (refine.py:243,373-375), far looser, so it reports such fits as converged. */
+  if (!out.ok && it == maxiter && gain <= STALL_TOL && (m == 0 || l1norm(cv, m) <= 1e-10)) out.ok = 1;
   out.S = S;
 done:
   free(g); free(A); free(gt); free(At); free(H); free(vt); free(dl); free(w);
-  free(Y); free(Cj); free(Cjt); free(fr);
+  free(Y); free(Cj); free(Cjt); free(fr); free(Q); free(Qt); free(B);
   return out;
 }
 
@@ -677,7 +779,7 @@ int ctro_objective(const ctr_problem* p, const ctr_batch* b, int64_t cl, double*
   pack_start(&c, params, b->low + (size_t)f0 * np, b->high + (size_t)f0 * np, vect, lo, hi);
   if (v_in) memcpy(vect, v_in, sizeof(double) * c.L.nv); /* evaluate elsewhere, masks stay at p0 */
   A = malloc(sizeof(double) * c.L.nv * c.L.nv);
-  eval_cluster(&c, vect, &S, grad, A, &P);
+  eval_cluster(&c, vect, &S, grad, A, NULL, &P);
   {
     const double fm = fmax[b->frame_index[cl]];
     const double norm = fm * fm / p->residual_factor;
