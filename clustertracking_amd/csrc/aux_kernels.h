@@ -4,6 +4,40 @@
 #ifndef CTREFINE_AUX_KERNELS_H
 #define CTREFINE_AUX_KERNELS_H
 
+// Order of the clusters inside every bin for one call: clusters with two features closer
+// than a quarter of the mask radius (scaled distance, as find.py:72-93 scales by the
+// separation) and clusters of more than 8 features go to the front of their bin.  Those
+// are the fits that take tens of iterations and several re-window rounds; a bin lasts
+// as long as its slowest cluster, so they must start first.  The results do not depend on
+// the order.
+struct FrontArgs { int begin[16]; int count[16]; int nbins; int keep_bin; /* bin copied as it is */ };
+
+__global__ void front_load_kernel(const KArgs k, const FrontArgs fa, const int* __restrict__ order_in,
+                                  int* __restrict__ order_out, int* __restrict__ counters, int total) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  int b = 0;
+  for (int j = 1; j < fa.nbins; ++j)
+    if (t >= fa.begin[j]) b = j;
+  const int cl = order_in[t];
+  const int f0 = k.feat_offset[cl], n = k.feat_offset[cl + 1] - f0;
+  if (b == fa.keep_bin) { order_out[t] = cl; return; }  // the bulk of singles keeps its (frame) order
+  const int np = k.prob.n_params, nd = k.prob.ndim;
+  bool close = n > 8;
+  for (int i = 0; i < n && !close; ++i)
+    for (int j = i + 1; j < n && !close; ++j) {
+      double d2 = 0.;
+      for (int a = 0; a < nd; ++a) {
+        const double d = (k.params[(size_t)(f0 + i) * np + 2 + a] - k.params[(size_t)(f0 + j) * np + 2 + a]) /
+                         (double)k.prob.radius[a];
+        d2 += d * d;
+      }
+      if (d2 < 0.0625) close = true;
+    }
+  const int pos = close ? atomicAdd(&counters[2 * b], 1) : fa.count[b] - 1 - atomicAdd(&counters[2 * b + 1], 1);
+  order_out[fa.begin[b] + pos] = cl;
+}
+
 // clusters the engine cannot take (too many variables / features)
 __global__ void mark_kernel(const KArgs k, int code) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -46,9 +46,12 @@ __device__ __forceinline__ double readlane_f64(double x, int srclane) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <int NR, class QF>
+// nwt: add the exact second-order part.  qk[kr] is the entry between this lane's variable
+// and the variable of kind kr (0 signal, 1 + a position) of the same feature; ic = vinfo[c].
+template <int NR, int NK>
 __device__ __forceinline__ bool column_solve(const double* Mp, int nv, double mu, bool is_free,
-                                             int lane, double& x_own, bool nwt, QF qvar) {
+                                             int lane, double& x_own, bool nwt, const int* vinfo,
+                                             int ic, const double (&qk)[NK]) {
   const int c = lane;
   const bool colv = c < nv && is_free;
   const unsigned long long fmask = __ballot(colv);
@@ -57,9 +60,14 @@ __device__ __forceinline__ bool column_solve(const double* Mp, int nv, double mu
   for (int i = 0; i < NR; ++i) {
     const bool rowv = ((fmask >> i) & 1ull) != 0ull;
     double x = 0., xq = 0.;
-    if (rowv && colv) {
-      x = Msym(Mp, i + 1, c + 1);
-      if (nwt) xq = qvar(i, c);   // exact second-order part of the model Hessian
+    if (rowv && colv) x = Msym(Mp, i + 1, c + 1);
+    if (nwt) {
+      const int ir = vinfo[i];   // same address in every lane
+      const int kr = (ir & 7) - 1;
+      double q = qk[0];
+#pragma unroll
+      for (int t = 1; t < NK; ++t) q = kr == t ? qk[t] : q;
+      xq = (rowv && colv && ic >= 0 && ((ir ^ ic) >> 3) == 0 && kr >= 0) ? q : 0.;
     }
     // Marquardt scaling by the Gauss-Newton diagonal in both models
     if (i == c) x = colv ? x + xq + mu * (x > 1e-300 ? x : 1.) : 1.;
@@ -71,7 +79,8 @@ __device__ __forceinline__ bool column_solve(const double* Mp, int nv, double mu
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
-    if (j < nv) {  // rows beyond the variables are identity: nothing to eliminate (uniform branch)
+    if (j < nv && ok) {  // rows beyond the variables are identity: nothing to eliminate; a failed
+                         // pivot ends the factorisation (both conditions are wave-uniform)
       const double dj = readlane_f64(col[j], j);
       if (!(dj > 0.) || !isfinite(dj)) ok = false;
       const double dinv = fast_rsqrt(dj);
@@ -90,7 +99,7 @@ __device__ __forceinline__ bool column_solve(const double* Mp, int nv, double mu
   x_own = 0.;
 #pragma unroll
   for (int j = NR - 1; j >= 0; --j) {
-    if (j < nv) {
+    if (j < nv && ok) {
       const double xj = readlane_f64((yown - s) * mydinv, j);
       if (c == j) x_own = xj;
       s += (c < j ? col[j] * mydinv : 0.) * xj;
@@ -136,7 +145,7 @@ __device__ __forceinline__ void make_layout_b(const ctr_problem& p, int n, Layou
   L.nv = ns + n * np;
 }
 
-constexpr int QT = 8;  // second-order sums kept per feature: U[a<=b], 3 (2D) or 6 (3D) used
+constexpr int QT = 9;  // second-order entries kept per feature: ND (signal, pos_a) + ND(ND+1)/2 (pos_a, pos_b)
 
 template <int NT, int W>
 struct SmemB {
@@ -144,7 +153,8 @@ struct SmemB {
   static constexpr int RS = NVP + 1;
   static constexpr int NTILE = NT * (NT + 1) / 2;
   static constexpr int NF = NVP < MAXF ? NVP : MAXF;
-  static constexpr int NVC = NVP < 32 ? NVP : 32;
+  // constraint Jacobians: constrained clusters have 2..4 features = at most 29 variables (NT <= 2)
+  static constexpr int NVC = NT <= 2 ? NVP : 1;
   static constexpr int ROWS = WAVE * RS;               // one wave's row tile
   static constexpr int o_rows = 0;                      // W row tiles; tile 0 doubles as packed H
   static constexpr int o_M = o_rows + W * ROWS;
@@ -165,14 +175,14 @@ struct SmemB {
   static constexpr int o_fr = o_small + 64;
   static constexpr int o_part = o_fr + NVP / 2 + 2;     // per wave: S, P
   static constexpr int o_ctl = o_part + 2 * W;          // ints: phase, origin[3], wshape[3]
-  // second-order sums of the current point, QT per feature (features with >= 3 variables each)
+  // second-order entries of the current point, QT per feature (features with >= 3 variables each)
   static constexpr int NFQ = (NVP + 2) / 3 < MAXF ? (NVP + 2) / 3 : MAXF;
   static constexpr int o_uc = o_ctl + 8;
-  static constexpr int o_vinfo = o_uc + NFQ * QT;       // ints: feature and kind of every variable
-  static constexpr int o_cpair = o_vinfo + NVP;         // ints: pair behind constraint r (current, trial)
+  static constexpr int o_vinfo = o_uc + NFQ * QT;       // ints: 8 * feature + kind + 1 of every variable
+  static constexpr int o_cpair = o_vinfo + NVP / 2;     // ints: pair behind constraint r (current, trial)
   static constexpr int total = o_cpair + MAXC;
   static constexpr size_t bytes = (size_t)total * sizeof(double);
-  static_assert(W == 1 || NTILE * 256 + QT * WAVE <= ROWS, "partial accumulators must fit a row tile");
+  static_assert(W == 1 || NTILE * 256 + 6 * WAVE <= ROWS, "partial accumulators must fit a row tile");
 };
 
 enum { BP_EVAL_INIT = 1, BP_EVAL_TRIAL = 2, BP_STEP_ONLY = 3, BP_FINISH = 4 };
@@ -258,8 +268,9 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
   int* fr = (int*)(smem + SM::o_fr);
   int* ctl = (int*)(smem + SM::o_ctl);
   double* Uc = smem + SM::o_uc;
-  int* vfeat = (int*)(smem + SM::o_vinfo);   // feature of variable c, -1 for a shared one
-  int* vkind = vfeat + SM::NVP;              // 0 signal, 1 + a position axis a, -1 anything else
+  // 8 * feature + kind + 1 of variable c (kind: 0 signal, 1 + a position axis a, -1 anything
+  // else); negative for a shared variable
+  int* vinfo = (int*)(smem + SM::o_vinfo);
   int* cpair = (int*)(smem + SM::o_cpair);   // [0..5] current point, [6..11] trial
   double* myrows = smem + SM::o_rows + wave * SM::ROWS;
 
@@ -404,9 +415,9 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
     if (!isfinite(x)) finite = false;
   }
   for (int e = tid; e < W * SM::ROWS; e += WAVE * W) smem[SM::o_rows + e] = 0.;
-  for (int c = tid; c < nv; c += WAVE * W) {
+  for (int c = tid; c < SM::NVP; c += WAVE * W) {
     int fi = -1, kind = -1;
-    if (c >= L.nshared) {
+    if (c >= L.nshared && c < nv) {
       fi = (c - L.nshared) / L.npf;
       const int sl = c - L.nshared - fi * L.npf;
       if (L.per_feat[1] && sl == L.slot[1]) kind = 0;
@@ -414,8 +425,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
       for (int a = 0; a < ND; ++a)
         if (L.per_feat[2 + a] && sl == L.slot[2 + a]) kind = 1 + a;
     }
-    vfeat[c] = fi;
-    vkind[c] = kind;
+    vinfo[c] = fi < 0 ? -1 : 8 * fi + kind + 1;
   }
   for (int e = tid; e < n * 3; e += WAVE * W) {
     const int i = e / 3, a = e % 3;
@@ -805,10 +815,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         for (int i = lane; i < nv; i += WAVE) v[i] = vt[i];
         for (int e = lane; e < m * LDC; e += WAVE) Cj[e] = Cjt[e];
         if (lane < m) { cv[lane] = cvt[lane]; cpair[lane] = cpair[MAXC + lane]; }
-        if (newton_on && lane < n) {
-#pragma unroll
-          for (int t = 0; t < NUF; ++t) Uc[lane * QT + t] = uacc[t];
-        }
+
         // acc -> packed lower triangle; D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
         {
           const int cc = lane & 15, r0 = lane >> 4;
@@ -826,6 +833,30 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             }
         }
         S = St;
+        wsync();
+        if (newton_on && lane < n) {
+          // second-order entries of feature `lane` at the new point: U from the pixel pass,
+          // the rest from the gradient (oracle eval_cluster): d2res/ds dpos_a = g_pos_a / s,
+          // d2res/dpos_a dpos_b = U_ab + delta_ab (-ND/size_a^2) s g_s
+          const int cs = L.vidx(1, lane);
+          const double sig = v[cs], gs = Mp[tri(cs + 1)];
+          int e = 0;
+#pragma unroll
+          for (int a = 0; a < ND; ++a) {
+            const double ga = Mp[tri(L.vidx(2 + a, lane) + 1)];
+            Uc[lane * QT + a] = sig != 0. ? ga / sig : 0.;
+#pragma unroll
+            for (int b2 = a; b2 < ND; ++b2) {
+              double u = uacc[e];
+              if (b2 == a) {
+                const double sz = par(v, lane, ISO ? 2 + ND : 2 + ND + a);
+                u += -(double)ND / (sz * sz) * sig * gs;
+              }
+              Uc[lane * QT + ND + e] = u;
+              ++e;
+            }
+          }
+        }
         wsync();
       }
       STAMP(2);
@@ -885,27 +916,21 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           double stepmax = 0., sigma_t = sigma;
           // second-order part between two variables (0 unless both belong to one feature)
           auto qvar = [&](int gi, int gj) -> double {
-            const int fi = vfeat[gi];
-            if (fi < 0 || fi != vfeat[gj]) return 0.;
-            int ka = vkind[gi], kb = vkind[gj];
-            if (ka < 0 || kb < 0) return 0.;
-            if (ka > kb) { const int t = ka; ka = kb; kb = t; gj = gi; }   // gj: variable of the larger kind
-            const int cs = L.vidx(1, fi);
-            const double sig = v[cs];
-            if (ka == 0) return kb == 0 ? 0. : (sig != 0. ? Mp[tri(gj + 1)] / sig : 0.);
-            const int a2 = ka - 1, b2 = kb - 1;
-            double u = Uc[fi * QT + (a2 * ND - (a2 * (a2 - 1)) / 2 + (b2 - a2))];
-            if (a2 == b2) {
-              const double sz = par(v, fi, ISO ? 2 + ND : 2 + ND + a2);
-              u += -(double)ND / (sz * sz) * sig * Mp[tri(cs + 1)];
-            }
-            return u;
+            const int ia = vinfo[gi], ib = vinfo[gj];
+            const int ka = (ia & 7) - 1, kb = (ib & 7) - 1;
+            const bool hit = ia >= 0 && ((ia ^ ib) >> 3) == 0 && ka >= 0 && kb >= 0 && ka + kb > 0;
+            const int k0 = ka < kb ? ka : kb, k1 = ka < kb ? kb : ka;   // 0 signal, 1 + a position
+            int idx = k0 == 0 ? k1 - 1 : ND + ((k0 - 1) * ND - ((k0 - 1) * (k0 - 2)) / 2 + (k1 - k0));
+            idx = hit ? (ia >> 3) * QT + idx : 0;
+            const double q = Uc[idx];
+            return hit ? q : 0.;
           };
           // curvature of the constraints between two position variables of the same axis
           auto ccurv = [&](int gi, int gj) -> double {
-            const int ka = vkind[gi];
-            if (ka < 1 || ka != vkind[gj]) return 0.;
-            const int fi = vfeat[gi], fj = vfeat[gj];
+            const int ia = vinfo[gi], ib = vinfo[gj];
+            const int ka = (ia & 7) - 1;
+            if (ia < 0 || ib < 0 || ka < 1 || ka != (ib & 7) - 1) return 0.;
+            const int fi = ia >> 3, fj = ib >> 3;
             const double da = k.prob.constraint_dist[ka - 1];
             double t = 0.;
 #pragma unroll
@@ -921,6 +946,22 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             }
             return t;
           };
+          // register solve: the second-order entries of this lane's variable, by kind of the
+          // other variable of its feature
+          const int ic = (reg_solve && newton_on && lane < nv) ? vinfo[lane] : -1;
+          double qk[ND + 1];
+          {
+            const int kc = (ic & 7) - 1;
+#pragma unroll
+            for (int kr = 0; kr <= ND; ++kr) {
+              const int k0 = kr < kc ? kr : kc, k1 = kr < kc ? kc : kr;
+              const bool valid = ic >= 0 && kc >= 0 && kr + kc > 0;
+              const int idx = k0 == 0 ? k1 - 1 : ND + ((k0 - 1) * ND - ((k0 - 1) * (k0 - 2)) / 2 + (k1 - k0));
+              const double q = Uc[valid ? (ic >> 3) * QT + idx : 0];
+              qk[kr] = valid ? q : 0.;
+            }
+          }
+          STAMP(8);
 #pragma nounroll
           for (int attempt = newton_on ? 1 : 0; attempt >= 0 && !ok_step; --attempt) {
             const bool nwt = attempt == 1;
@@ -933,14 +974,14 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
               // unrolled to the next multiple of four rows (the identity rows beyond the
               // variables would otherwise be eliminated too: work grows with the square)
               if (NT == 1) {
-                if (nv <= 8) ok_a = column_solve<8>(Mp, nv, mu, is_free, lane, x_own, nwt, qvar);
-                else if (nv <= 12) ok_a = column_solve<12>(Mp, nv, mu, is_free, lane, x_own, nwt, qvar);
-                else ok_a = column_solve<16>(Mp, nv, mu, is_free, lane, x_own, nwt, qvar);
+                if (nv <= 8) ok_a = column_solve<8>(Mp, nv, mu, is_free, lane, x_own, nwt, vinfo, ic, qk);
+                else if (nv <= 12) ok_a = column_solve<12>(Mp, nv, mu, is_free, lane, x_own, nwt, vinfo, ic, qk);
+                else ok_a = column_solve<16>(Mp, nv, mu, is_free, lane, x_own, nwt, vinfo, ic, qk);
               } else {
-                if (nv <= 20) ok_a = column_solve<20>(Mp, nv, mu, is_free, lane, x_own, nwt, qvar);
-                else if (nv <= 24) ok_a = column_solve<24>(Mp, nv, mu, is_free, lane, x_own, nwt, qvar);
-                else if (nv <= 28) ok_a = column_solve<28>(Mp, nv, mu, is_free, lane, x_own, nwt, qvar);
-                else ok_a = column_solve<32>(Mp, nv, mu, is_free, lane, x_own, nwt, qvar);
+                if (nv <= 20) ok_a = column_solve<20>(Mp, nv, mu, is_free, lane, x_own, nwt, vinfo, ic, qk);
+                else if (nv <= 24) ok_a = column_solve<24>(Mp, nv, mu, is_free, lane, x_own, nwt, vinfo, ic, qk);
+                else if (nv <= 28) ok_a = column_solve<28>(Mp, nv, mu, is_free, lane, x_own, nwt, vinfo, ic, qk);
+                else ok_a = column_solve<32>(Mp, nv, mu, is_free, lane, x_own, nwt, vinfo, ic, qk);
               }
               if (ok_a && lane < nv) dl[lane] = -x_own;
               wsync();
@@ -1020,6 +1061,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
                 }
               }
             }
+            STAMP(9);
             if (!ok_a) continue;
             if (!have_dl) {
               for (int i = lane; i < nv; i += WAVE) dl[i] = 0.;
@@ -1043,12 +1085,20 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             }
             wsync();
             stepmax = wave_max(stepmax);
+            STAMP(10);
             double partial = 0.;
             for (int i = lane; i < nv; i += WAVE) {
               double t = 0.;
               for (int j = 0; j < nv; ++j) t += Msym(Mp, i + 1, j + 1) * dl[j];
-              if (nwt && vfeat[i] >= 0) {
-                const int j0 = L.nshared + vfeat[i] * L.npf;
+              if (nwt && reg_solve) {
+                if (ic >= 0) {   // one variable per lane here: i == lane
+                  const int j0 = L.nshared + (ic >> 3) * L.npf;
+                  t += qk[0] * dl[j0 + L.slot[1]];
+#pragma unroll
+                  for (int a = 0; a < ND; ++a) t += qk[1 + a] * dl[j0 + L.slot[2 + a]];
+                }
+              } else if (nwt && vinfo[i] >= 0) {
+                const int j0 = L.nshared + (vinfo[i] >> 3) * L.npf;
                 for (int j = j0; j < j0 + L.npf; ++j) t += qvar(i, j) * dl[j];
                 if (m)
                   for (int j = L.nshared; j < nv; ++j) t += ccurv(i, j) * dl[j];
@@ -1072,11 +1122,11 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             }
             pred = bcast0(pred);
             stepmax = bcast0(stepmax);
+            STAMP(11);
             if (nwt && !(pred > -tiny)) continue;
             ok_step = true;
           }
-          sigma = bcast0(sigma_t);
-          cn_pred = bcast0(cn_pred);
+          sigma = sigma_t;   // uniform: computed from LDS data by every lane alike
           STAMP(4);
           if (!ok_step) {
             mu *= nu; nu *= 2.; last_acc = false;

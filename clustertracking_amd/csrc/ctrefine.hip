@@ -38,15 +38,17 @@ namespace {
 
 // ---- host side ------------------------------------------------------------------------
 
+constexpr size_t LDS_CU = 160 * 1024;  // LDS of one CU
+
 typedef void (*kernel_fn)(const KArgs);
 typedef void (*small_fn)(const KArgs, int*);
 
-template <int NT> struct WavesFor { static constexpr int value = NT == 2 ? 8 : (NT <= 3 ? 4 : (NT <= 6 ? 2 : 1)); };
+template <int NT> struct WavesFor { static constexpr int value = NT <= 2 ? 8 : (NT <= 3 ? 4 : (NT <= 6 ? 2 : 1)); };
 
 template <int ND, bool ISO, int NT>
 void fill_one(kernel_fn* t, size_t* bytes, int* threads) {
   constexpr int W = WavesFor<NT>::value;
-  static_assert(SmemB<NT, W>::bytes <= 160 * 1024, "LDS budget of one CU");
+  static_assert(SmemB<NT, W>::bytes <= LDS_CU, "LDS budget of one CU");
   t[NT - 1] = refine_block_kernel<ND, ISO, NT, W>;
   bytes[NT - 1] = SmemB<NT, W>::bytes;
   threads[NT - 1] = WAVE * W;
@@ -78,7 +80,8 @@ struct ctr_plan {
   ctr_problem prob;
   int64_t n_clusters = 0;
   int device = 0;
-  int32_t* d_order = nullptr;  // all bins back to back
+  int32_t* d_order = nullptr;  // all bins back to back; second copy [n_clusters..2n): the order of one call
+  int* d_front = nullptr;      // 2 * NBINS counters of front_load_kernel
   int64_t bin_begin[NBINS + 1] = {0};
   int64_t bin_count[NBINS] = {0};
 };
@@ -101,8 +104,8 @@ struct ctr_handle {
   bool attr_set[2][2][MAXNT] = {};
   small_fn small_table[2][2][2];  // [ndim-2][iso][nf-1]; singles with 16 lanes per cluster
   small_fn small_wide1[2][2];     // singles with 64 lanes per cluster (large windows)
-  hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {nullptr, nullptr, nullptr};
+  hipStream_t side[NSIDE] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {};
   int* d_counter = nullptr;       // work counters of the small-kernel launches
 };
 
@@ -331,13 +334,13 @@ int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
   }
   if (n_clusters > 0) {
     if (hipSetDevice(h->device) != hipSuccess ||
-        hipMalloc((void**)&plan->d_order, sizeof(int32_t) * (size_t)n_clusters) != hipSuccess) {
-      delete plan;
+        hipMalloc((void**)&plan->d_order, sizeof(int32_t) * 2 * (size_t)n_clusters) != hipSuccess ||
+        hipMalloc((void**)&plan->d_front, sizeof(int) * 2 * NBINS) != hipSuccess) {
+      ctr_plan_destroy(plan);
       return fail(h, CTR_ERR_NOMEM, "cannot allocate the plan on the device");
     }
     if (hipMemcpy(plan->d_order, order.data(), sizeof(int32_t) * (size_t)n_clusters, hipMemcpyHostToDevice) != hipSuccess) {
-      (void)hipFree(plan->d_order);
-      delete plan;
+      ctr_plan_destroy(plan);
       return fail(h, CTR_ERR_DEVICE, "cannot upload the plan");
     }
   }
@@ -348,6 +351,7 @@ int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
 void ctr_plan_destroy(ctr_plan* plan) {
   if (!plan) return;
   if (plan->d_order) { (void)hipSetDevice(plan->device); (void)hipFree(plan->d_order); }
+  if (plan->d_front) (void)hipFree(plan->d_front);
   delete plan;
 }
 
@@ -400,8 +404,19 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
   // The bins are independent: the big bin of singles runs on the caller's
   // stream, the others on side streams forked from / joined to it by events, so
   // that a few slow many-feature clusters overlap with the bulk.
+  // this call's order inside the bins: likely stragglers first (front_load_kernel)
+  int32_t* ord = plan->d_order + plan->n_clusters;
+  {
+    FrontArgs fa;
+    fa.nbins = NBINS;
+    fa.keep_bin = BIN_SMALL1;
+    for (int bin = 0; bin < NBINS; ++bin) { fa.begin[bin] = (int)plan->bin_begin[bin]; fa.count[bin] = (int)plan->bin_count[bin]; }
+    HIP_TRY(h, hipMemsetAsync(plan->d_front, 0, sizeof(int) * 2 * NBINS, s));
+    hipLaunchKernelGGL(front_load_kernel, dim3((unsigned)((plan->n_clusters + 255) / 256)), dim3(256), 0, s, k, fa,
+                       plan->d_order, ord, plan->d_front, (int)plan->n_clusters);
+  }
   HIP_TRY(h, hipEventRecord(h->ev_fork, s));
-  bool used[NSIDE] = {false, false, false};
+  bool used[NSIDE] = {};
   int next_side = 0;
   auto pick_stream = [&](bool main_stream) -> hipStream_t {
     if (main_stream) return s;
@@ -419,13 +434,13 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
       HIP_TRY(h, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
       h->attr_set[di][ii][bin] = true;
     }
-    k.order = plan->d_order + plan->bin_begin[bin];
+    k.order = ord + plan->bin_begin[bin];
     k.n_bin = (int32_t)cnt;
     hipLaunchKernelGGL(fn, dim3((unsigned)cnt), dim3((unsigned)h->block_threads[di][ii][bin]), bytes, pick_stream(false), k);
   }
   if (plan->bin_count[BIN_TOO_LARGE] > 0) {
     const int64_t cnt = plan->bin_count[BIN_TOO_LARGE];
-    k.order = plan->d_order + plan->bin_begin[BIN_TOO_LARGE];
+    k.order = ord + plan->bin_begin[BIN_TOO_LARGE];
     k.n_bin = (int32_t)cnt;
     hipLaunchKernelGGL(mark_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, pick_stream(false), k,
                        (int)CTR_STATUS_TOO_LARGE);
@@ -437,7 +452,7 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     hipStream_t st = pick_stream(nf == 1);
     int* counter = h->d_counter + nf;
     HIP_TRY(h, hipMemsetAsync(counter, 0, sizeof(int), st));
-    k.order = plan->d_order + plan->bin_begin[bin];
+    k.order = ord + plan->bin_begin[bin];
     k.n_bin = (int32_t)cnt;
     // lanes per cluster by the size of a single-feature window: 16 (four clusters per
     // wave) while a window is a few passes, 64 once it is thousands of pixels (3D)
