@@ -38,6 +38,15 @@ __global__ void front_load_kernel(const KArgs k, const FrontArgs fa, const int* 
   order_out[fa.begin[b] + pos] = cl;
 }
 
+// Head start for the workgroups that need a large contiguous piece of LDS (block kernel):
+// the small kernels allocate ~1 KB of LDS per wave all over every CU, and once they have
+// flooded the machine a 70..150 KB request finds no contiguous room until they drain.
+// One wave that waits `ticks` of the 100 MHz clock, ahead of the small kernels in their streams.
+__global__ void delay_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 // clusters the engine cannot take (too many variables / features)
 __global__ void mark_kernel(const KArgs k, int code) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;

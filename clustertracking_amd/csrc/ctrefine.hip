@@ -75,6 +75,7 @@ std::mutex g_mutex;
 // MAXNT+1 / MAXNT+2 = singles / pairs with default modes (small kernel)
 constexpr int BIN_TOO_LARGE = MAXNT, BIN_SMALL1 = MAXNT + 1, BIN_SMALL2 = MAXNT + 2, NBINS = MAXNT + 3;
 constexpr int NSIDE = 3;  // side streams for concurrent bin launches
+constexpr int GATE_US = 20;  // head start of the block kernels over the small kernels (delay_kernel)
 
 struct ctr_plan {
   ctr_problem prob;
@@ -105,7 +106,7 @@ struct ctr_handle {
   small_fn small_table[2][2][2];  // [ndim-2][iso][nf-1]; singles with 16 lanes per cluster
   small_fn small_wide1[2][2];     // singles with 64 lanes per cluster (large windows)
   hipStream_t side[NSIDE] = {};
-  hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {};
+  hipEvent_t ev_fork = nullptr, ev_gate = nullptr, ev_join[NSIDE] = {};
   int* d_counter = nullptr;       // work counters of the small-kernel launches
 };
 
@@ -244,7 +245,8 @@ int ctr_create(ctr_handle** out, int device) {
     if (hipEventCreate(&ev) != hipSuccess) { delete h; return fail(nullptr, CTR_ERR_DEVICE, "hipEventCreate failed"); }
   for (auto& st : h->side)
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(nullptr, CTR_ERR_DEVICE, "cannot create side streams"); }
-  bool evok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+  bool evok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_gate, hipEventDisableTiming) == hipSuccess;
   for (auto& ev : h->ev_join) evok = evok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
   if (!evok || hipMalloc((void**)&h->d_counter, sizeof(int) * 8) != hipSuccess) { delete h; return fail(nullptr, CTR_ERR_DEVICE, "cannot create events / counters"); }
   h->small_wide1[0][1] = refine_small_kernel<2, 1, true, 64>;
@@ -277,6 +279,7 @@ void ctr_destroy(ctr_handle* h) {
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& st : h->side) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_gate) (void)hipEventDestroy(h->ev_gate);
   for (auto& ev : h->ev_join) if (ev) (void)hipEventDestroy(ev);
   if (h->d_counter) (void)hipFree(h->d_counter);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -445,11 +448,19 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     hipLaunchKernelGGL(mark_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, pick_stream(false), k,
                        (int)CTR_STATUS_TOO_LARGE);
   }
+  // the small kernels start a little later than the block kernels (see delay_kernel)
+  bool gate = false;
+  for (int bin = 0; bin < MAXNT; ++bin) gate = gate || plan->bin_count[bin] > 0;
+  if (gate) {
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(WAVE), 0, s, (unsigned long long)GATE_US * 100ull);
+    HIP_TRY(h, hipEventRecord(h->ev_gate, s));
+  }
   for (int nf = 2; nf >= 1; --nf) {
     const int bin = nf == 1 ? BIN_SMALL1 : BIN_SMALL2;
     const int64_t cnt = plan->bin_count[bin];
     if (cnt == 0) continue;
     hipStream_t st = pick_stream(nf == 1);
+    if (gate && nf != 1) (void)hipStreamWaitEvent(st, h->ev_gate, 0);
     int* counter = h->d_counter + nf;
     HIP_TRY(h, hipMemsetAsync(counter, 0, sizeof(int), st));
     k.order = ord + plan->bin_begin[bin];
@@ -476,6 +487,11 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
 }
 
 #ifdef CTR_STAMPS
+#ifdef CTR_DBG_CL
+int ctr_debug_starts(unsigned long long* out4096) {
+  return hipMemcpyFromSymbol(out4096, HIP_SYMBOL(g_dbg_start), sizeof(unsigned long long) * 4096) != hipSuccess;
+}
+#endif
 int ctr_debug_stamps(unsigned long long* out16, int reset) {
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
   if (reset) {

@@ -12,8 +12,14 @@ hb = prep.batch
 sz = np.diff(hb.feat_offset)
 eng = _lib.default_engine(0)
 import torch
-for lo_n, hi_n in ((1, 1), (2, 2), (3, 4), (5, 100), (1, 100)):
-    sel = np.flatnonzero((sz >= lo_n) & (sz <= hi_n))
+import itertools
+classes = [(1, 1), (2, 2), (3, 4), (5, 100)]
+sets = [[c] for c in classes] + [list(x) for x in itertools.combinations(classes, 2)] + [list(x) for x in itertools.combinations(classes, 3)] + [classes]
+for cls in sets:
+    mask = np.zeros(len(sz), bool)
+    for lo_n, hi_n in cls:
+        mask |= (sz >= lo_n) & (sz <= hi_n)
+    sel = np.flatnonzero(mask)
     rows = np.concatenate([np.arange(hb.feat_offset[c], hb.feat_offset[c + 1]) for c in sel])
     off = np.concatenate([[0], np.cumsum(sz[sel])])
     sub = _abi.HostBatch(hb.frames, hb.frame_index[sel], off, hb.params[rows], hb.low[rows], hb.high[rows])
@@ -23,5 +29,5 @@ for lo_n, hi_n in ((1, 1), (2, 2), (3, 4), (5, 100), (1, 100)):
         db.run(); eng.synchronize(None); torch.cuda.synchronize()
         ts.append(eng.last_kernel_ms()[1])
     db.download()
-    print('sizes %d-%d: %6d clusters, %7d iterations (max %d): refine stage %.3f ms' % (
-        lo_n, hi_n, len(sel), sub.n_iter.sum(), sub.n_iter.max(), np.median(ts[1:])))
+    print('sizes %-40s %6d clusters, %7d iterations (max %d): refine stage %.3f ms' % (
+        '+'.join('%d-%d' % c for c in cls) + ':', len(sel), sub.n_iter.sum(), sub.n_iter.max(), np.median(ts[1:])))
