@@ -15,27 +15,54 @@ struct FrontArgs { int begin[16]; int count[16]; int nbins; int keep_bin; /* bin
 __global__ void front_load_kernel(const KArgs k, const FrontArgs fa, const int* __restrict__ order_in,
                                   int* __restrict__ order_out, int* __restrict__ counters, int total) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;
-  int b = 0;
-  for (int j = 1; j < fa.nbins; ++j)
-    if (t >= fa.begin[j]) b = j;
-  const int cl = order_in[t];
-  const int f0 = k.feat_offset[cl], n = k.feat_offset[cl + 1] - f0;
-  if (b == fa.keep_bin) { order_out[t] = cl; return; }  // the bulk of singles keeps its (frame) order
-  const int np = k.prob.n_params, nd = k.prob.ndim;
-  bool close = n > 8;
-  for (int i = 0; i < n && !close; ++i)
-    for (int j = i + 1; j < n && !close; ++j) {
-      double d2 = 0.;
-      for (int a = 0; a < nd; ++a) {
-        const double d = (k.params[(size_t)(f0 + i) * np + 2 + a] - k.params[(size_t)(f0 + j) * np + 2 + a]) /
-                         (double)k.prob.radius[a];
-        d2 += d * d;
-      }
-      if (d2 < 0.0625) close = true;
+  const int lane = threadIdx.x & 63;
+  int b = -1, cl = 0;
+  bool close = false;
+  if (t < total) {
+    b = 0;
+    for (int j = 1; j < fa.nbins; ++j)
+      if (t >= fa.begin[j]) b = j;
+    cl = order_in[t];
+    if (b == fa.keep_bin) {   // the bulk of singles keeps its (frame) order
+      order_out[t] = cl;
+      b = -1;
+    } else {
+      const int f0 = k.feat_offset[cl], n = k.feat_offset[cl + 1] - f0;
+      const int np = k.prob.n_params, nd = k.prob.ndim;
+      close = n > 8;
+      for (int i = 0; i < n && !close; ++i)
+        for (int j = i + 1; j < n && !close; ++j) {
+          double d2 = 0.;
+          for (int a = 0; a < nd; ++a) {
+            const double d = (k.params[(size_t)(f0 + i) * np + 2 + a] - k.params[(size_t)(f0 + j) * np + 2 + a]) /
+                             (double)k.prob.radius[a];
+            d2 += d * d;
+          }
+          if (d2 < 0.0625) close = true;
+        }
     }
-  const int pos = close ? atomicAdd(&counters[2 * b], 1) : fa.count[b] - 1 - atomicAdd(&counters[2 * b + 1], 1);
-  order_out[fa.begin[b] + pos] = cl;
+  }
+  // one pair of atomics per wave and bin instead of one per cluster (all on two addresses)
+  unsigned long long todo = __ballot(b >= 0);
+  while (todo != 0ull) {
+    const int leader = __builtin_ctzll(todo);
+    const int lb = __shfl(b, leader);
+    const unsigned long long same = __ballot(b == lb);
+    const unsigned long long mc = __ballot(b == lb && close), mf = same & ~mc;
+    int basec = 0, basef = 0;
+    if (lane == leader) {
+      basec = atomicAdd(&counters[2 * lb], __popcll(mc));
+      basef = atomicAdd(&counters[2 * lb + 1], __popcll(mf));
+    }
+    basec = __shfl(basec, leader);
+    basef = __shfl(basef, leader);
+    if (b == lb) {
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const int pos = close ? basec + __popcll(mc & below) : fa.count[lb] - 1 - (basef + __popcll(mf & below));
+      order_out[fa.begin[lb] + pos] = cl;
+    }
+    todo &= ~same;
+  }
 }
 
 // Head start for the workgroups that need a large contiguous piece of LDS (block kernel):

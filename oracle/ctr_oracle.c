@@ -795,3 +795,45 @@ int ctro_objective(const ctr_problem* p, const ctr_batch* b, int64_t cl, double*
   free(A); free(fmax); free(coords);
   return c.L.nv;
 }
+
+/* Model Hessian of F at v_in (masks at the start coordinates, as ctro_objective):
+ * hess[nv*nv] = 2 (J^T J + Q) / (P norm), with Q the exact second-order part that solve()
+ * adds for (signal, positions) of every feature when exact != 0.  Test hook: a finite
+ * difference of ctro_objective's gradient must reproduce it.  Returns nv. */
+int ctro_hessian(const ctr_problem* p, const ctr_batch* b, int64_t cl, const double* v_in,
+                 int exact, double* hess) {
+  const int32_t f0 = b->feat_offset[cl], f1 = b->feat_offset[cl + 1];
+  const int n = f1 - f0, np = p->n_params, nd = p->ndim;
+  const double* params = b->params + (size_t)f0 * np;
+  ctx_t c;
+  size_t felems = 1;
+  double lo[MAXV], hi[MAXV], vect[MAXV], grad[MAXV], S;
+  long P;
+  double* fmax = malloc(sizeof(double) * (size_t)b->n_frames);
+  double* coords = malloc(sizeof(double) * (size_t)n * nd);
+  c.p = p; c.b = b;
+  if (make_layout(p, n, &c.L) > MAXV) { free(fmax); free(coords); return -1; }
+  frame_max(b, nd, fmax);
+  for (int a = 0; a < nd; ++a) felems *= (size_t)b->shape[a];
+  c.frame = (const char*)b->frames + (size_t)b->frame_index[cl] * felems * dtype_size(b->frame_dtype);
+  c.n_cons = 0;
+  c.pconst = params;
+  for (int i = 0; i < n; ++i)
+    for (int a = 0; a < nd; ++a) coords[i * nd + a] = params[i * np + 2 + a];
+  if (!window(nd, b->shape, p->radius, coords, n, c.origin, c.wshape)) { free(fmax); free(coords); return -2; }
+  c.mcoords = coords;
+  pack_start(&c, params, b->low + (size_t)f0 * np, b->high + (size_t)f0 * np, vect, lo, hi);
+  if (v_in) memcpy(vect, v_in, sizeof(double) * c.L.nv);
+  {
+    const int nv = c.L.nv;
+    double* A = malloc(sizeof(double) * nv * nv);
+    double* Q = calloc((size_t)nv * nv, sizeof(double));
+    eval_cluster(&c, vect, &S, grad, A, exact ? Q : NULL, &P);
+    const double fm = fmax[b->frame_index[cl]];
+    const double norm = fm * fm / p->residual_factor;
+    for (int i = 0; i < nv * nv; ++i) hess[i] = 2. * (A[i] + Q[i]) / (double)P / norm;
+    free(A); free(Q);
+  }
+  free(fmax); free(coords);
+  return c.L.nv;
+}

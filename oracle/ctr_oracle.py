@@ -102,3 +102,22 @@ def objective(problem, batch, cluster, v_in=None):
     nd = problem.ndim
     return (F.value, vect[:nv], grad[:nv], bounds[:nv], tuple(origin[:nd]),
             tuple(wshape[:nd]), P.value)
+
+
+def hessian(problem, batch, cluster, v_in=None, exact=True):
+    """Model Hessian of F at ``v_in`` (or the packed start vector): 2 (J^T J + Q) / (P norm),
+    Q = the exact second-order part of solve() for (signal, positions); exact=False -> J^T J only."""
+    from clustertracking_amd import _abi
+    lib = load()
+    b = batch.as_struct()
+    H = np.zeros((_abi.MAX_VARS, _abi.MAX_VARS))
+    lib.ctro_hessian.argtypes = [C.POINTER(_abi.Problem), C.POINTER(_abi.Batch), C.c_int64, C.c_void_p,
+                                 C.c_int, C.c_void_p]
+    lib.ctro_hessian.restype = C.c_int
+    nv = lib.ctro_hessian(C.byref(problem), C.byref(b), int(cluster),
+                          None if v_in is None else
+                          np.ascontiguousarray(v_in, dtype=np.float64).ctypes.data,
+                          int(bool(exact)), H.ctypes.data)
+    if nv < 0:
+        raise ValueError("ctro_hessian failed (%d)" % nv)
+    return H.reshape(-1)[:nv * nv].reshape(nv, nv).copy()

@@ -305,61 +305,7 @@ def test_refine_with_device_labels_matches_reference_labels(engine):
 
 # ---- randomized configurations: every kernel variant against the oracle ------------------
 
-def _random_case(seed):
-    rng = np.random.RandomState(seed)
-    ndim = int(rng.choice([2, 3], p=[0.7, 0.3]))
-    iso = bool(rng.rand() < 0.5)
-    if ndim == 2:
-        shape = tuple(rng.randint(60, 120, 2))
-        size = rng.uniform(2.5, 4.5) if iso else tuple(rng.uniform(2.5, 4.5, 2))
-        n = rng.randint(3, 30)
-    else:
-        shape = tuple(rng.randint(24, 44, 3))
-        size = rng.uniform(2., 3.) if iso else tuple(rng.uniform(2., 3.2, 3))
-        n = rng.randint(2, 9)
-    sz = np.broadcast_to(size, (ndim,))
-    diameter = int(4 * sz[0]) | 1 if iso else tuple(int(4 * s) | 1 for s in sz)
-    if not iso and len(set(diameter)) == 1:   # equal diameters would mean isotropic (utils.py:52-56)
-        diameter = (diameter[0] + 2,) + tuple(diameter[1:])
-    margin = tuple(int(2 * s) + 2 for s in sz)
-    dtype = [np.uint8, np.uint16, np.float32, np.float64][rng.randint(4)]
-    im, truth, p0 = cta.artificial.random_frame(shape, n, size, 100, int(rng.choice([0, 10])),
-                                                seed, margin=margin)
-    im = im.astype(dtype)
-    f0 = pd.DataFrame(p0 + rng.uniform(-0.7, 0.7, p0.shape), columns=['z', 'y', 'x'][-ndim:])
-    f0['signal'] = 90.
-    if iso:
-        f0['size'] = float(size) * rng.uniform(0.9, 1.1)
-    else:
-        for c, s in zip(['size_z', 'size_y', 'size_x'][-ndim:], sz):
-            f0[c] = s * rng.uniform(0.9, 1.1)
-    if rng.rand() < 0.7:
-        f0['background'] = 4.
-    modes = {}
-    r = rng.rand()
-    if r < 0.25:
-        modes['size'] = 'var'
-    elif r < 0.4:
-        modes['size'] = 'cluster'
-    r = rng.rand()
-    if r < 0.15:
-        modes['signal'] = 'cluster'
-    elif r < 0.25:
-        modes['signal'] = 'const'
-    if rng.rand() < 0.1:
-        modes['background'] = 'const'
-    kw = dict(param_mode=modes or None)
-    if rng.rand() < 0.3:
-        kw['bounds'] = dict(signal=(20., 400.), pos_diff=float(rng.uniform(1.5, 4.)),
-                            size_rel_diff=0.4)
-    if rng.rand() < 0.25:
-        kind = ['dimer', 'trimer', 'tetramer'][rng.randint(3)]
-        kw['constraints'] = getattr(cta.constraints, kind)(2. * np.asarray(sz, float), ndim)
-    if rng.rand() < 0.3:
-        kw['separation'] = tuple(float(d) * 1.6 for d in np.broadcast_to(diameter, (ndim,)))
-    if rng.rand() < 0.2:
-        kw['max_iter'] = int(rng.randint(1, 4))
-    return f0, im, diameter, kw
+_random_case = _cases.random_case
 
 
 @pytest.mark.parametrize("block", range(6))

@@ -13,15 +13,11 @@ from clustertracking import constraints as ref_cons
 import clustertracking_amd as cta
 import _cases
 
-src = open(os.path.join(ROOT, 'tests', 'test_gpu_parity.py')).read()
-ns = {}
-exec(src[src.index("def _random_case"):src.index("@pytest.mark.parametrize(\"block\"")],
-     {'np': np, 'pd': pd, 'cta': cta}, ns)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 9000
 worst = 0.
 for seed in range(first, first + n):
-    f0, im, diameter, kw = ns['_random_case'](seed)
+    f0, im, diameter, kw = _cases.random_case(seed)
     kw_ref = dict(kw)
     if 'constraints' in kw:
         c = kw['constraints'][0]

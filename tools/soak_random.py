@@ -9,11 +9,8 @@ import pandas as pd
 import clustertracking_amd as cta
 from clustertracking_amd import _abi, _lib
 import ctr_oracle
+import _cases
 
-src = open(os.path.join(ROOT, 'tests', 'test_gpu_parity.py')).read()
-ns = {}
-exec(src[src.index("def _random_case"):src.index("@pytest.mark.parametrize(\"block\"")],
-     {'np': np, 'pd': pd, 'cta': cta}, ns)
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 eng = _lib.default_engine(0)
@@ -21,7 +18,7 @@ bad = 0
 n_clusters = 0
 worst = 0.
 for seed in range(first, first + n_seeds):
-    f0, im, diameter, kw = ns['_random_case'](seed)
+    f0, im, diameter, kw = _cases.random_case(seed)
     prep = cta.prepare_batch(f0, im, diameter, **kw)
     b = prep.batch
     ref = _abi.HostBatch(b.frames, b.frame_index, b.feat_offset, b.params, b.low, b.high)
