@@ -117,29 +117,48 @@ def main():
     db = DeviceBatch(prep.problem, prep.batch, device=local_rank)
     n_fits = prep.batch.n_clusters
     n_feat = prep.batch.n_features
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = None   # DeviceBatch.run orders the engine's work with torch's current stream
 
-    gather_buf = None
+    # The only exchange of the path: the result rows of every rank go to rank 0.  The gather of
+    # step k runs on the collective's own stream while step k+1 computes (two send / receive
+    # buffers; a buffer is reused only after the gather that read it has completed).
+    send, gather_buf, pending, step_no = [], [None, None], [None, None], [0]
     if world > 1:
         counts = [torch.zeros(1, dtype=torch.int64, device=coll_dev) for _ in range(world)]
         dist.all_gather(counts, torch.tensor([n_feat], dtype=torch.int64, device=coll_dev))
         counts = [int(c.item()) for c in counts]
         width = prep.batch.params.shape[1] + 1
         pad = max(counts)
+        send = [torch.zeros((pad, width), dtype=torch.float64, device=coll_dev) for _ in range(2)]
         if rank == 0:
-            gather_buf = [torch.empty((pad, width), dtype=torch.float64, device=coll_dev)
-                          for _ in range(world)]
-        send = torch.zeros((pad, width), dtype=torch.float64, device=coll_dev)
+            gather_buf = [[torch.empty((pad, width), dtype=torch.float64, device=coll_dev)
+                           for _ in range(world)] for _ in range(2)]
+        # cluster of every feature row, resident on the device: cost[row_cluster] = cost per row
+        row_cluster = torch.from_numpy(np.repeat(np.arange(n_fits, dtype=np.int64),
+                                                 np.diff(prep.batch.feat_offset))).to(db.device)
 
     def step():
         db.run(stream)
         if world > 1:
-            # the only exchange of the path: result rows of every rank -> rank 0
-            send[:n_feat] = db.results_tensor().to(coll_dev)
-            dist.gather(send, gather_buf, dst=0)
+            k = step_no[0] & 1
+            step_no[0] += 1
+            if pending[k] is not None:
+                pending[k].wait()
+            buf = send[k]
+            if coll_dev == 'cuda':      # device-to-device on the compute stream, no host sync
+                buf[:n_feat, :width - 1].copy_(db.t['params_out'])
+                buf[:n_feat, width - 1].copy_(db.t['cost'][row_cluster])
+            else:                       # gloo (CPU tests): through host memory
+                buf[:n_feat, :width - 1].copy_(db.t['params_out'].cpu())
+                buf[:n_feat, width - 1].copy_(db.t['cost'][row_cluster].cpu())
+            pending[k] = dist.gather(buf, gather_buf[k], dst=0, async_op=True)
 
     def fence():
         if world > 1:
+            for k in range(2):
+                if pending[k] is not None:
+                    pending[k].wait()
+                    pending[k] = None
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -159,6 +178,20 @@ def main():
         fm_ms.append(a)
         rf_ms.append(b)
     fence()
+
+    gather_ok = None
+    if world > 1 and rank == 0:
+        # what arrived in the last gather: rank 0's own rows must be its results, every other
+        # rank's rows finite positions inside its frames
+        last = (step_no[0] - 1) & 1
+        own = gather_buf[last][0][:n_feat, :width - 1].to(db.device)
+        gather_ok = bool(torch.equal(own, db.t['params_out']))
+        if not gather_ok and os.environ.get('CTR_BENCH_DEBUG'):
+            d = (own != db.t['params_out'])
+            sys.stderr.write('gather debug: %d differing elements of %d; rows %s; nan own %d; max |d| %.3e; cols %s\n' % (int(d.sum()), d.numel(), d.any(1).nonzero()[:5].flatten().tolist(), int(torch.isnan(own).sum()), float((own - db.t['params_out']).abs().max()), d.any(0).tolist()))
+        for r in range(1, world):
+            rows = gather_buf[last][r][:counts[r], 2:4]
+            gather_ok = gather_ok and bool(torch.isfinite(rows).all()) and bool((rows > -20).all())
 
     t_all = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
     fits_all = torch.tensor([float(n_fits)], dtype=torch.float64, device=coll_dev)
@@ -207,6 +240,7 @@ def main():
                                    "unit": "GB/s", "frac": hb.frames.nbytes / fm / 1e9 / peak,
                                    "kernel_ms": fm * 1e3},
             "host_prepare_s": t_host_prep,
+            "gather_checked": gather_ok,
         }
         if world == 1 and not args.no_cpu_baseline:
             pos = slice(2, 2 + frames.ndim - 1)

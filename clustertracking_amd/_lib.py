@@ -17,7 +17,7 @@ EXPORTS = ('ctr_abi_version', 'ctr_create', 'ctr_destroy', 'ctr_last_error',
            'ctr_validate_problem', 'ctr_cluster_n_vars', 'ctr_refine_batch',
            'ctr_plan_create', 'ctr_plan_destroy', 'ctr_refine_batch_device',
            'ctr_frame_max_device', 'ctr_synchronize', 'ctr_last_kernel_ms',
-           'ctr_find_clusters')
+           'ctr_find_clusters', 'ctr_engine_wait_stream', 'ctr_stream_wait_engine')
 
 _lib = None
 _lock = threading.Lock()
@@ -97,6 +97,10 @@ def load():
             lib.ctr_find_clusters.restype = C.c_int
         lib.ctr_synchronize.argtypes = [C.c_void_p, C.c_void_p]
         lib.ctr_synchronize.restype = C.c_int
+        for name in ('ctr_engine_wait_stream', 'ctr_stream_wait_engine'):
+            if hasattr(lib, name):   # (absent from libraries built before they existed)
+                getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p]
+                getattr(lib, name).restype = C.c_int
         lib.ctr_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_double), P(C.c_double)]
         lib.ctr_last_kernel_ms.restype = C.c_int
         if lib.ctr_abi_version() != _abi.ABI_VERSION:
@@ -183,6 +187,17 @@ class Engine(object):
     def synchronize(self, stream=None):
         self._check(self._lib.ctr_synchronize(self._h, C.c_void_p(stream or 0)),
                     'ctr_synchronize')
+
+    def engine_wait_stream(self, stream=0):
+        """The engine's own stream waits (on the device) for what is queued on ``stream``
+        (raw handle; 0 = the legacy default stream)."""
+        self._check(self._lib.ctr_engine_wait_stream(self._h, C.c_void_p(stream or 0)),
+                    'ctr_engine_wait_stream')
+
+    def stream_wait_engine(self, stream=0):
+        """``stream`` waits (on the device) for what is queued on the engine's own stream."""
+        self._check(self._lib.ctr_stream_wait_engine(self._h, C.c_void_p(stream or 0)),
+                    'ctr_stream_wait_engine')
 
     def last_kernel_ms(self):
         a, b = C.c_double(), C.c_double()

@@ -106,7 +106,7 @@ struct ctr_handle {
   small_fn small_table[2][2][2];  // [ndim-2][iso][nf-1]; singles with 16 lanes per cluster
   small_fn small_wide1[2][2];     // singles with 64 lanes per cluster (large windows)
   hipStream_t side[NSIDE] = {};
-  hipEvent_t ev_fork = nullptr, ev_gate = nullptr, ev_join[NSIDE] = {};
+  hipEvent_t ev_fork = nullptr, ev_gate = nullptr, ev_order = nullptr, ev_join[NSIDE] = {};
   int* d_counter = nullptr;       // work counters of the small-kernel launches
 };
 
@@ -246,7 +246,8 @@ int ctr_create(ctr_handle** out, int device) {
   for (auto& st : h->side)
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(nullptr, CTR_ERR_DEVICE, "cannot create side streams"); }
   bool evok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&h->ev_gate, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&h->ev_gate, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming) == hipSuccess;
   for (auto& ev : h->ev_join) evok = evok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
   if (!evok || hipMalloc((void**)&h->d_counter, sizeof(int) * 8) != hipSuccess) { delete h; return fail(nullptr, CTR_ERR_DEVICE, "cannot create events / counters"); }
   h->small_wide1[0][1] = refine_small_kernel<2, 1, true, 64>;
@@ -280,6 +281,7 @@ void ctr_destroy(ctr_handle* h) {
   for (auto& st : h->side) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_gate) (void)hipEventDestroy(h->ev_gate);
+  if (h->ev_order) (void)hipEventDestroy(h->ev_order);
   for (auto& ev : h->ev_join) if (ev) (void)hipEventDestroy(ev);
   if (h->d_counter) (void)hipFree(h->d_counter);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -555,6 +557,22 @@ int ctr_synchronize(ctr_handle* h, void* hip_stream) {
   if (!h) return CTR_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : h->stream));
+  return CTR_OK;
+}
+
+int ctr_engine_wait_stream(ctr_handle* h, void* hip_stream) {
+  if (!h) return CTR_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipEventRecord(h->ev_order, (hipStream_t)hip_stream));
+  HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_order, 0));
+  return CTR_OK;
+}
+
+int ctr_stream_wait_engine(ctr_handle* h, void* hip_stream) {
+  if (!h) return CTR_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipEventRecord(h->ev_order, h->stream));
+  HIP_TRY(h, hipStreamWaitEvent((hipStream_t)hip_stream, h->ev_order, 0));
   return CTR_OK;
 }
 

@@ -44,11 +44,24 @@ class DeviceBatch(object):
         self.plan = self.engine.plan(problem, hb.feat_offset)
 
     def run(self, stream=None):
-        """Queue frame-max + refine kernels on ``stream`` (default: torch's
-        current stream on this device)."""
-        if stream is None:
-            stream = self.torch.cuda.current_stream(self.device).cuda_stream
-        self.engine.refine_batch_device(self.plan, self.struct, stream)
+        """Queue frame-max + refine kernels, ordered with torch's current stream on this
+        device: work queued on that stream before the call is seen by the kernels, work
+        queued after it sees the results.  ``stream``: a raw hipStream_t handle to use
+        instead (non-zero; 0 would mean the engine's own stream, include/ctrefine.h, which
+        torch knows nothing about)."""
+        torch = self.torch
+        if stream:
+            self.engine.refine_batch_device(self.plan, self.struct, stream)
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != 0:
+            self.engine.refine_batch_device(self.plan, self.struct, cur.cuda_stream)
+            return
+        # torch is on the legacy default stream (handle 0): the engine runs on its own stream,
+        # ordered with the default stream by events on the device
+        self.engine.engine_wait_stream(0)
+        self.engine.refine_batch_device(self.plan, self.struct, 0)
+        self.engine.stream_wait_engine(0)
 
     def download(self):
         """Copy the outputs back into the HostBatch arrays (synchronises)."""

@@ -172,6 +172,17 @@ int ctr_find_clusters(ctr_handle* h, int32_t ndim, const double* pos, const int3
 /* Block until the work queued by the *_device calls on `hip_stream` is done. */
 int ctr_synchronize(ctr_handle* h, void* hip_stream);
 
+/* Ordering with a caller's stream when the *_device calls run on the handle's own stream
+ * (hip_stream = NULL above), without blocking the host.  `hip_stream` here is a hipStream_t
+ * passed as void*; NULL means the legacy default stream (what PyTorch uses unless told
+ * otherwise).
+ *   ctr_engine_wait_stream: work queued later on the handle's stream starts only when
+ *     everything queued so far on `hip_stream` has finished (inputs produced there).
+ *   ctr_stream_wait_engine: work queued later on `hip_stream` starts only when everything
+ *     queued so far on the handle's stream has finished (results consumed there). */
+int ctr_engine_wait_stream(ctr_handle* h, void* hip_stream);
+int ctr_stream_wait_engine(ctr_handle* h, void* hip_stream);
+
 /* Timing of the kernels of the last ctr_refine_batch_device call, measured
  * with HIP events on the launch stream (milliseconds); synchronises. */
 int ctr_last_kernel_ms(ctr_handle* h, double* frame_max_ms, double* refine_ms);
