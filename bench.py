@@ -23,6 +23,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Every size class of a batch is one kernel on its own stream, and several batches are in
+# flight (--in-flight): that needs more hardware queues than ROCm's default of 4 per process,
+# or kernels of different streams queue up behind each other.  Read by the HIP runtime when it
+# initialises, hence set here, before torch is imported.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+
 import numpy as np  # noqa: E402
 
 
@@ -41,6 +47,12 @@ def parse():
                          "the N > 1 code path on a one-GPU box)")
     ap.add_argument('--features', type=int, default=None,
                     help="features per frame/stack (default: the workload's own)")
+    ap.add_argument('--in-flight', type=int, default=4,
+                    help="batches in flight per GPU: step k starts while the slowest clusters of "
+                         "steps k-1.. are still being fitted (one engine handle and one set of "
+                         "output buffers per batch in flight)")
+    ap.add_argument('--shard', type=int, default=None,
+                    help="rehearsal on one GPU: take the frames rank SHARD of a multi-GPU run would get")
     ap.add_argument('--single-device', action='store_true',
                     help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
@@ -92,21 +104,22 @@ def main():
             dist.init_process_group('gloo', rank=rank, world_size=world)
 
     # ---- this rank's shard: frames [rank*F, (rank+1)*F) of the video --------------
+    shard = rank if args.shard is None else args.shard
     extra = {}
     if args.workload == 'cfg2':
-        frames, f0, truth, opts = workloads.cfg2(args.frames, first_seed=rank * args.frames)
+        frames, f0, truth, opts = workloads.cfg2(args.frames, first_seed=shard * args.frames)
         wl_text = ("cfg2: %d frames/GPU of 512x512 uint8, 200 Gaussians/frame, size 3 (radius of "
                    "gyration), diameter 13, Poisson noise 10, isotropic Gaussian model, default "
                    "param modes" % args.frames)
     elif args.workload == 'cfg3':
         nfeat = args.features or 500
-        frames, f0, truth, opts = workloads.cfg3(args.frames, first_seed=rank * args.frames,
+        frames, f0, truth, opts = workloads.cfg3(args.frames, first_seed=shard * args.frames,
                                                  n_features=nfeat)
         wl_text = ("cfg3: %d stacks/GPU of 64x128x128 uint8, %d Gaussians/stack, size (2,4,4), "
                    "diameter (9,17,17), anisotropic Gaussian model, default param modes"
                    % (args.frames, nfeat))
     else:
-        frames, f0, truth, opts = workloads.cfg5(args.frames, first_seed=rank * args.frames)
+        frames, f0, truth, opts = workloads.cfg5(args.frames, first_seed=shard * args.frames)
         extra['constraints'] = cta.constraints.dimer(6., 2)
         wl_text = ("cfg5: %d frames/GPU of 512x512 uint8, 36 compact clusters of 2/8-16 Gaussians, "
                    "size 3, diameter 13, dimers constrained to 2*size" % args.frames)
@@ -114,53 +127,71 @@ def main():
     t0 = time.perf_counter()
     prep = cta.prepare_batch(f0, reader, opts['diameter'], **extra)
     t_host_prep = time.perf_counter() - t0
-    db = DeviceBatch(prep.problem, prep.batch, device=local_rank)
+    from clustertracking_amd import _lib
+    nfl = max(1, args.in_flight)
+    engines = [_lib.default_engine(local_rank)] + [_lib.Engine(local_rank) for _ in range(nfl - 1)]
+    dbs = [DeviceBatch(prep.problem, prep.batch, device=local_rank, engine=e) for e in engines]
+    db = dbs[0]
     n_fits = prep.batch.n_clusters
     n_feat = prep.batch.n_features
-    stream = None   # DeviceBatch.run orders the engine's work with torch's current stream
 
-    # The only exchange of the path: the result rows of every rank go to rank 0.  The gather of
-    # step k runs on the collective's own stream while step k+1 computes (two send / receive
-    # buffers; a buffer is reused only after the gather that read it has completed).
-    send, gather_buf, pending, step_no = [], [None, None], [None, None], [0]
+    # A step = one pass of the hot path over the batch.  Steps go round robin over the
+    # engines; an engine's own stream keeps its steps in order, different engines overlap
+    # on the GPU, so the slowest clusters of one step (a bin lasts as long as its slowest
+    # cluster) no longer hold up the next steps.
+    # The only exchange of the path: the result rows of every rank go to rank 0.  The rows of
+    # a step are staged and gathered on a stream of their own per engine, behind that step
+    # only; a staging buffer is reused when the gather that read it has completed.
+    send, gather_buf, pending, tstreams, step_no = [], [], [None] * nfl, [], [0]
     if world > 1:
         counts = [torch.zeros(1, dtype=torch.int64, device=coll_dev) for _ in range(world)]
         dist.all_gather(counts, torch.tensor([n_feat], dtype=torch.int64, device=coll_dev))
         counts = [int(c.item()) for c in counts]
         width = prep.batch.params.shape[1] + 1
         pad = max(counts)
-        send = [torch.zeros((pad, width), dtype=torch.float64, device=coll_dev) for _ in range(2)]
-        if rank == 0:
-            gather_buf = [[torch.empty((pad, width), dtype=torch.float64, device=coll_dev)
-                           for _ in range(world)] for _ in range(2)]
+        send = [torch.zeros((pad, width), dtype=torch.float64, device=coll_dev) for _ in range(nfl)]
+        gather_buf = [[torch.empty((pad, width), dtype=torch.float64, device=coll_dev)
+                       for _ in range(world)] if rank == 0 else None for _ in range(nfl)]
+        tstreams = [torch.cuda.Stream(db.device) for _ in range(nfl)]
         # cluster of every feature row, resident on the device: cost[row_cluster] = cost per row
         row_cluster = torch.from_numpy(np.repeat(np.arange(n_fits, dtype=np.int64),
                                                  np.diff(prep.batch.feat_offset))).to(db.device)
 
     def step():
-        db.run(stream)
-        if world > 1:
-            k = step_no[0] & 1
-            step_no[0] += 1
+        k = step_no[0] % nfl
+        step_no[0] += 1
+        d = dbs[k]
+        if world == 1:
+            d.engine.refine_batch_device(d.plan, d.struct, 0)   # the engine's own stream
+            return
+        ts = tstreams[k]
+        with torch.cuda.stream(ts):
             if pending[k] is not None:
-                pending[k].wait()
+                pending[k].wait()                       # the gather that read send[k] is done
+        d.engine.engine_wait_stream(ts.cuda_stream)     # ... and the staging that read params_out
+        d.engine.refine_batch_device(d.plan, d.struct, 0)
+        d.engine.stream_wait_engine(ts.cuda_stream)     # staging starts when this step is done
+        with torch.cuda.stream(ts):
             buf = send[k]
-            if coll_dev == 'cuda':      # device-to-device on the compute stream, no host sync
-                buf[:n_feat, :width - 1].copy_(db.t['params_out'])
-                buf[:n_feat, width - 1].copy_(db.t['cost'][row_cluster])
-            else:                       # gloo (CPU tests): through host memory
-                buf[:n_feat, :width - 1].copy_(db.t['params_out'].cpu())
-                buf[:n_feat, width - 1].copy_(db.t['cost'][row_cluster].cpu())
+            if coll_dev == 'cuda':      # device-to-device, no host sync
+                buf[:n_feat, :width - 1].copy_(d.t['params_out'])
+                buf[:n_feat, width - 1].copy_(d.t['cost'][row_cluster])
+            else:                       # gloo (rehearsal on one box): through host memory
+                buf[:n_feat, :width - 1].copy_(d.t['params_out'].cpu())
+                buf[:n_feat, width - 1].copy_(d.t['cost'][row_cluster].cpu())
             pending[k] = dist.gather(buf, gather_buf[k], dst=0, async_op=True)
 
     def fence():
         if world > 1:
-            for k in range(2):
+            for k in range(nfl):
                 if pending[k] is not None:
-                    pending[k].wait()
+                    with torch.cuda.stream(tstreams[k]):
+                        pending[k].wait()
                     pending[k] = None
-            dist.barrier()
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -173,17 +204,21 @@ def main():
     elapsed = time.perf_counter() - t0
     # kernel durations: HIP events recorded on the launch stream inside the library
     for _ in range(5):
-        db.run(stream)
+        db.run()
         a, b = db.engine.last_kernel_ms()
         fm_ms.append(a)
         rf_ms.append(b)
     fence()
 
+    # every batch in flight must have produced the same table
+    ran = min(nfl, step_no[0])
+    copies_same = all(bool(torch.equal(db.t['params_out'], d.t['params_out'])) and
+                      bool(torch.equal(db.t['status'], d.t['status'])) for d in dbs[1:ran])
     gather_ok = None
     if world > 1 and rank == 0:
         # what arrived in the last gather: rank 0's own rows must be its results, every other
         # rank's rows finite positions inside its frames
-        last = (step_no[0] - 1) & 1
+        last = (step_no[0] - 1) % nfl
         own = gather_buf[last][0][:n_feat, :width - 1].to(db.device)
         gather_ok = bool(torch.equal(own, db.t['params_out']))
         if not gather_ok and os.environ.get('CTR_BENCH_DEBUG'):
@@ -241,6 +276,8 @@ def main():
                                    "kernel_ms": fm * 1e3},
             "host_prepare_s": t_host_prep,
             "gather_checked": gather_ok,
+            "batches_in_flight": nfl,
+            "in_flight_results_identical": copies_same,
         }
         if world == 1 and not args.no_cpu_baseline:
             pos = slice(2, 2 + frames.ndim - 1)
