@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 # flight (--in-flight): that needs more hardware queues than ROCm's default of 4 per process,
 # or kernels of different streams queue up behind each other.  Read by the HIP runtime when it
 # initialises, hence set here, before torch is imported.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '32')
 
 import numpy as np  # noqa: E402
 

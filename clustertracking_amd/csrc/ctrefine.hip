@@ -74,7 +74,7 @@ std::mutex g_mutex;
 // bins: 0..MAXNT-1 generic kernel by NT-1; MAXNT = too large for the engine;
 // MAXNT+1 / MAXNT+2 = singles / pairs with default modes (small kernel)
 constexpr int BIN_TOO_LARGE = MAXNT, BIN_SMALL1 = MAXNT + 1, BIN_SMALL2 = MAXNT + 2, NBINS = MAXNT + 3;
-constexpr int NSIDE = 3;  // side streams for concurrent bin launches
+constexpr int NSIDE = 4;  // side streams for concurrent bin launches
 constexpr int GATE_US = 20;  // head start of the block kernels over the small kernels (delay_kernel)
 
 struct ctr_plan {
@@ -105,6 +105,7 @@ struct ctr_handle {
   bool attr_set[2][2][MAXNT] = {};
   small_fn small_table[2][2][2];  // [ndim-2][iso][nf-1]; singles with 16 lanes per cluster
   small_fn small_wide1[2][2];     // singles with 64 lanes per cluster (large windows)
+  small_fn small_bulk2[2][2];     // pairs with 16 lanes per cluster (the bulk of a pairs bin)
   hipStream_t side[NSIDE] = {};
   hipEvent_t ev_fork = nullptr, ev_gate = nullptr, ev_order = nullptr, ev_join[NSIDE] = {};
   int* d_counter = nullptr;       // work counters of the small-kernel launches
@@ -254,6 +255,10 @@ int ctr_create(ctr_handle** out, int device) {
   h->small_wide1[0][0] = refine_small_kernel<2, 1, false, 64>;
   h->small_wide1[1][1] = refine_small_kernel<3, 1, true, 64>;
   h->small_wide1[1][0] = refine_small_kernel<3, 1, false, 64>;
+  h->small_bulk2[0][1] = refine_small_kernel<2, 2, true, 16>;
+  h->small_bulk2[0][0] = refine_small_kernel<2, 2, false, 16>;
+  h->small_bulk2[1][1] = refine_small_kernel<3, 2, true, 16>;
+  h->small_bulk2[1][0] = refine_small_kernel<3, 2, false, 16>;
   h->small_table[0][1][0] = refine_small_kernel<2, 1, true, 16>;
   h->small_table[0][1][1] = refine_small_kernel<2, 2, true, 64>;
   h->small_table[0][0][0] = refine_small_kernel<2, 1, false, 16>;
@@ -388,7 +393,7 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
   HIP_TRY(h, hipEventRecord(h->ev[1], s));
 
   KArgs k;
-  std::memset(&k, 0, sizeof k);
+  std::memset(&k, 0, sizeof k);   // (split = nullptr: a launch takes its whole bin)
   k.prob = p;
   k.frames = b->frames;
   k.frame_dtype = b->frame_dtype;
@@ -474,8 +479,29 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     const bool wide = nf == 2 || vol > 600;
     small_fn fn = nf == 2 ? h->small_table[di][ii][1] : (wide ? h->small_wide1[di][ii] : h->small_table[di][ii][0]);
     int64_t waves = wide ? cnt : (cnt + 3) / 4;
+    if (nf == 2 && vol <= 600 && cnt >= 64) {
+      // Pairs in two tiers.  One wavefront per pair gives the shortest iteration, which is
+      // what the slow fits need; for the rest, four pairs per wavefront cost a third of the
+      // machine time.  front_load_kernel has put the pairs closer than a quarter of the mask
+      // radius first and counted them (on the device): the 64-lane kernel takes exactly
+      // those, the 16-lane kernel, on a stream of its own, the others -- which kernel fits a
+      // pair depends on the pair alone, not on the order of the batch.
+      k.split = plan->d_front + 2 * bin;
+      hipStream_t sb = pick_stream(false);
+      if (gate) (void)hipStreamWaitEvent(sb, h->ev_gate, 0);
+      int* cbulk = h->d_counter + 3;
+      HIP_TRY(h, hipMemsetAsync(cbulk, 0, sizeof(int), sb));
+      k.split_part = 2;
+      int64_t wb = (cnt + 3) / 4;
+      if (wb > 8192) wb = 8192;
+      hipLaunchKernelGGL(h->small_bulk2[di][ii], dim3((unsigned)wb), dim3(WAVE), 0, sb, k, cbulk);
+      k.split_part = 1;
+      if (waves > 2048) waves = 2048;   // persistent: a wavefront takes pair after pair
+    }
     if (waves > 8192) waves = 8192;
     hipLaunchKernelGGL(fn, dim3((unsigned)waves), dim3(WAVE), 0, st, k, counter);
+    k.split = nullptr;
+    k.split_part = 0;
   }
   for (int j = 0; j < NSIDE; ++j)
     if (used[j]) {

@@ -35,6 +35,11 @@ struct KArgs {
   int32_t* n_iter;
   const double* fmax;
   const int32_t* order;  // cluster ids of this bin
+  // small kernel only: part of the bin a launch takes.  split == nullptr: all of it;
+  // split_part 1: entries [0, *split) (the likely slow fits, front_load_kernel's count),
+  // split_part 2: entries [*split, n_bin)
+  const int32_t* split;
+  int32_t split_part;
 };
 
 __device__ __forceinline__ size_t dtype_size(int dtype) {

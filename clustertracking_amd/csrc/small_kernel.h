@@ -83,7 +83,12 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
       int id = 0;
       if (sub == 0) id = atomicAdd(counter, 1);
       id = __shfl(id, lane & ~(SG - 1));
-      if (id >= k.n_bin) {
+      int id_end = k.n_bin;
+      if (k.split != nullptr) {
+        const int first = *k.split;
+        if (k.split_part == 1) id_end = first; else id += first;
+      }
+      if (id >= id_end) {
         phase = PH_DONE;
       } else {
         cl = k.order[id];
