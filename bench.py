@@ -127,8 +127,10 @@ def main():
     t0 = time.perf_counter()
     prep = cta.prepare_batch(f0, reader, opts['diameter'], **extra)
     t_host_prep = time.perf_counter() - t0
-    from clustertracking_amd import _lib
+    from clustertracking_amd import _lib, _abi
     nfl = max(1, args.in_flight)
+    if nfl > 1:     # several batches in flight: machine time per cluster before one-batch latency
+        prep.problem.flags |= _abi.FLAG_THROUGHPUT
     engines = [_lib.default_engine(local_rank)] + [_lib.Engine(local_rank) for _ in range(nfl - 1)]
     dbs = [DeviceBatch(prep.problem, prep.batch, device=local_rank, engine=e) for e in engines]
     db = dbs[0]

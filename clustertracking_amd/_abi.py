@@ -38,12 +38,15 @@ STATUS_TEXT = {
 }
 
 
+FLAG_THROUGHPUT = 1   # ctr_problem.flags (include/ctrefine.h): scheduling hint, results unchanged
+
+
 class Problem(C.Structure):
     _fields_ = [
         ('ndim', C.c_int32), ('isotropic', C.c_int32), ('fit_function', C.c_int32),
         ('n_params', C.c_int32), ('modes', C.c_int32 * MAX_PARAMS),
         ('radius', C.c_int32 * MAX_NDIM), ('constraint_kind', C.c_int32),
-        ('max_iter', C.c_int32), ('solver_maxiter', C.c_int32), ('reserved0', C.c_int32),
+        ('max_iter', C.c_int32), ('solver_maxiter', C.c_int32), ('flags', C.c_int32),
         ('constraint_dist', C.c_double * MAX_NDIM), ('max_shift', C.c_double),
         ('max_rms_dev', C.c_double), ('residual_factor', C.c_double),
         ('xtol', C.c_double), ('ftol', C.c_double), ('reserved1', C.c_double),

@@ -237,7 +237,6 @@ __device__ void chol_solve_w(const double* Lp, const double* dinv, int nf, doubl
 
 #ifdef CTR_STAMPS
 __device__ unsigned long long g_stamps[16];
-__device__ unsigned long long g_dbg_start[4096];
 #define STAMP(slot) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
     if (wave == 0 && lane == 0) atomicAdd(&g_stamps[slot], now_ - t_prev_); t_prev_ = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -248,15 +247,6 @@ template <int ND, bool ISO, int NT, int W>
 __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
 #ifdef CTR_STAMPS
   unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
-#endif
-#if defined(CTR_STAMPS) && defined(CTR_DBG_CL)
-  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
-  if (threadIdx.x == 0) {
-    atomicCAS(&g_stamps[14], 0ull, dbg_t0);
-    if (NT == 1 && blockIdx.x < 4096) g_dbg_start[blockIdx.x] = dbg_t0;
-    if (k.order[blockIdx.x] == CTR_DBG_CL) g_stamps[11] = blockIdx.x;
-    if (k.order[blockIdx.x] == CTR_DBG_CL) g_stamps[12] = dbg_t0;
-  }
 #endif
   using SM = SmemB<NT, W>;
   constexpr int NP = 2 + ND + (ISO ? 1 : ND);
@@ -1193,13 +1183,6 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
     STAMP(7);
   }
 
-#if defined(CTR_STAMPS) && defined(CTR_DBG_CL)
-  if (threadIdx.x == 0) {
-    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
-    atomicMax(&g_stamps[15], t1);
-    if (cl == CTR_DBG_CL) g_stamps[13] = t1;
-  }
-#endif
   if (wave == 0) {
     const bool ok = status == CTR_STATUS_OK;
     if (ok)

@@ -422,6 +422,9 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     fa.keep_bin = BIN_SMALL1;
     for (int bin = 0; bin < NBINS; ++bin) { fa.begin[bin] = (int)plan->bin_begin[bin]; fa.count[bin] = (int)plan->bin_count[bin]; }
     HIP_TRY(h, hipMemsetAsync(plan->d_front, 0, sizeof(int) * 2 * NBINS, s));
+    // the work counters of the small-kernel launches, here rather than in their streams: a
+    // fill kernel queued behind the gate would wait for a slot on a machine already flooded
+    HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(int) * 8, s));
     hipLaunchKernelGGL(front_load_kernel, dim3((unsigned)((plan->n_clusters + 255) / 256)), dim3(256), 0, s, k, fa,
                        plan->d_order, ord, plan->d_front, (int)plan->n_clusters);
   }
@@ -469,7 +472,6 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     hipStream_t st = pick_stream(nf == 1);
     if (gate && nf != 1) (void)hipStreamWaitEvent(st, h->ev_gate, 0);
     int* counter = h->d_counter + nf;
-    HIP_TRY(h, hipMemsetAsync(counter, 0, sizeof(int), st));
     k.order = ord + plan->bin_begin[bin];
     k.n_bin = (int32_t)cnt;
     // lanes per cluster by the size of a single-feature window: 16 (four clusters per
@@ -479,8 +481,9 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     const bool wide = nf == 2 || vol > 600;
     small_fn fn = nf == 2 ? h->small_table[di][ii][1] : (wide ? h->small_wide1[di][ii] : h->small_table[di][ii][0]);
     int64_t waves = wide ? cnt : (cnt + 3) / 4;
-    if (nf == 2 && vol <= 600 && cnt >= 64) {
-      // Pairs in two tiers.  One wavefront per pair gives the shortest iteration, which is
+    if (nf == 2 && vol <= 600 && cnt >= 64 && (p.flags & CTR_FLAG_THROUGHPUT) != 0) {
+      // Pairs in two tiers (CTR_FLAG_THROUGHPUT: +9 % with four batches in flight, but the
+      // one-batch-at-a-time step gets 12 % longer).  One wavefront per pair gives the shortest iteration, which is
       // what the slow fits need; for the rest, four pairs per wavefront cost a third of the
       // machine time.  front_load_kernel has put the pairs closer than a quarter of the mask
       // radius first and counted them (on the device): the 64-lane kernel takes exactly
@@ -489,8 +492,10 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
       k.split = plan->d_front + 2 * bin;
       hipStream_t sb = pick_stream(false);
       if (gate) (void)hipStreamWaitEvent(sb, h->ev_gate, 0);
+      // (a little later still than the first tier, whose few wavefronts must not queue up
+      // behind the thousands of this one)
+      hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(WAVE), 0, sb, (unsigned long long)GATE_US * 100ull);
       int* cbulk = h->d_counter + 3;
-      HIP_TRY(h, hipMemsetAsync(cbulk, 0, sizeof(int), sb));
       k.split_part = 2;
       int64_t wb = (cnt + 3) / 4;
       if (wb > 8192) wb = 8192;
@@ -515,11 +520,6 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
 }
 
 #ifdef CTR_STAMPS
-#ifdef CTR_DBG_CL
-int ctr_debug_starts(unsigned long long* out4096) {
-  return hipMemcpyFromSymbol(out4096, HIP_SYMBOL(g_dbg_start), sizeof(unsigned long long) * 4096) != hipSuccess;
-}
-#endif
 int ctr_debug_stamps(unsigned long long* out16, int reset) {
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
   if (reset) {

@@ -62,6 +62,12 @@ enum { CTR_MODE_CONST = 0, CTR_MODE_VAR = 1, CTR_MODE_GLOBAL = 2, CTR_MODE_CLUST
  * exactly 2 / 3 / 4 features (constraints.py:32-34) */
 enum { CTR_CONS_NONE = 0, CTR_CONS_DIMER = 1, CTR_CONS_TRIMER = 2, CTR_CONS_TETRAMER = 3 };
 
+/* ctr_problem.flags.  Scheduling only: the results do not depend on them.
+ * CTR_FLAG_THROUGHPUT: the caller keeps several batches in flight on one device (one handle
+ * each); favour machine time per cluster over the latency of one batch -- pairs that are not
+ * likely to be slow fits share a wavefront four at a time. */
+enum { CTR_FLAG_THROUGHPUT = 1 };
+
 /* per-cluster status */
 enum {
   CTR_STATUS_OK = 0,
@@ -85,7 +91,7 @@ typedef struct ctr_problem {
   int32_t constraint_kind;         /* CTR_CONS_* */
   int32_t max_iter;                /* re-window rounds, >= 1 (refine.py:365; default 10) */
   int32_t solver_maxiter;          /* solver iterations per round (refine.py:243; default 100) */
-  int32_t reserved0;
+  int32_t flags;                   /* CTR_FLAG_*; 0 = defaults */
   double constraint_dist[CTR_MAX_NDIM]; /* per-axis distance of the constraint */
   double max_shift;                /* refine.py:384 (default 1) */
   double max_rms_dev;              /* refine.py:391 (default 1) */

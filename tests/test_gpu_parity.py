@@ -4,6 +4,7 @@ CPU oracle and with the reference's golden outputs.  Needs a real MI355X.
 Tolerances (float64, pixels): engine vs C oracle 1e-7 px max (same algorithm,
 different summation order and exp implementation), cost 1e-10; engine vs the
 reference as in tests/test_golden_oracle.py."""
+import os
 import numpy as np
 import pandas as pd
 import pytest
@@ -94,6 +95,30 @@ def test_cfg2_full_size_vs_oracle_and_truth(engine, oracle, cfg2_full):
     okr[prep.order] = ok_rows
     rms = np.sqrt(np.mean((out[:, 2:4] - truth)[okr] ** 2))
     assert rms < 0.05, rms
+
+
+def test_cfg2_throughput_flag_changes_scheduling_not_results(engine, oracle, cfg2_full):
+    """CTR_FLAG_THROUGHPUT (include/ctrefine.h): the pairs that are not likely slow fits go
+    through the 16-lane kernel, four per wavefront.  Same statuses, iteration counts and
+    (to summation order) values as the default scheduling and as the oracle."""
+    import copy
+    prep, _ = cfg2_full
+    b0 = clone_batch(prep.batch)
+    b1 = clone_batch(prep.batch)
+    ref = clone_batch(prep.batch)
+    engine.refine_batch(prep.problem, b0)
+    prob = copy.copy(prep.problem)
+    prob.flags |= _abi.FLAG_THROUGHPUT
+    engine.refine_batch(prob, b1)
+    oracle.run_batch(prep.problem, ref, os.cpu_count() or 1)
+    assert_equal(b1.status, b0.status)
+    assert_equal(b1.n_iter, b0.n_iter)
+    assert_equal(b1.n_rounds, b0.n_rounds)
+    assert_allclose(b1.params_out, b0.params_out, rtol=0, atol=1e-9)
+    size = np.diff(prep.batch.feat_offset)
+    changed = (b1.cost != b0.cost) & (b0.status == 0)
+    assert set(np.unique(size[changed])) <= {2}      # only pairs took another kernel
+    assert_batches_close(b1, ref, slice(2, 4), atol=1e-6)
 
 
 def test_cfg2_cluster_order_invariance(engine, cfg2_full):
