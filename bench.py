@@ -23,11 +23,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Every size class of a batch is one kernel on its own stream, and several batches are in
-# flight (--in-flight): that needs more hardware queues than ROCm's default of 4 per process,
-# or kernels of different streams queue up behind each other.  Read by the HIP runtime when it
-# initialises, hence set here, before torch is imported.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '32')
 
 import numpy as np  # noqa: E402
 
@@ -79,6 +74,13 @@ def cpu_baseline(problem, host_batch):
 
 def main():
     args = parse()
+    # Every size class of a batch is one kernel on its own stream (5 streams per engine
+    # handle), and --in-flight batches are in flight: that needs more hardware queues than
+    # ROCm's default of 4 per process, or kernels of different streams queue up behind each
+    # other.  Read by the HIP runtime when it initialises, hence set before torch is imported.
+    # (Not more than needed: from 24 queues on, every small kernel of the chain -- fill,
+    # frame maximum, ordering -- takes ~0.1 ms instead of ~0.02 ms on this runtime.)
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', str(max(4, 5 * max(1, args.in_flight))))
     import torch
     import torch.distributed as dist
     import clustertracking_amd as cta
@@ -204,10 +206,15 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    # kernel durations: HIP events recorded on the launch stream inside the library
+    # kernel durations of ONE batch running alone, default scheduling (no throughput flag):
+    # HIP events recorded on the launch stream inside the library
+    import copy
+    prob_alone = copy.copy(prep.problem)
+    prob_alone.flags &= ~_abi.FLAG_THROUGHPUT
+    db_alone = DeviceBatch(prob_alone, prep.batch, device=local_rank, engine=engines[0]) if nfl > 1 else db
     for _ in range(5):
-        db.run()
-        a, b = db.engine.last_kernel_ms()
+        db_alone.run()
+        a, b = db_alone.engine.last_kernel_ms()
         fm_ms.append(a)
         rf_ms.append(b)
     fence()
@@ -248,8 +255,12 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = total_fits * args.steps / elapsed
         alg_bytes = db.algorithmic_bytes()
-        rf = float(np.median(rf_ms)) * 1e-3
+        rf_alone = float(np.median(rf_ms)) * 1e-3
         fm = float(np.median(fm_ms)) * 1e-3
+        # duration of the refine stage per launch: alone when one batch is in flight; with
+        # several in flight the stages of neighbouring steps overlap and one completes per
+        # step time (steady state)
+        rf = rf_alone if nfl == 1 else elapsed / args.steps
         peak = 8000.0
         traffic = None
         tf = os.path.join(ROOT, 'profiles', 'traffic_cfg2.json')
@@ -271,7 +282,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "refine stage: refine_small_kernel<2,1|2> + refine_block_kernel<2,iso,NT,W> (concurrent streams)",
                          "achieved": alg_bytes / rf / 1e9, "peak": peak, "unit": "GB/s",
                          "frac": alg_bytes / rf / 1e9 / peak, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": rf * 1e3},
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": rf * 1e3,
+                         "kernel_ms_one_batch_alone": rf_alone * 1e3},
             "roofline_frame_max": {"bound": "hbm", "kernel": "frame_max_kernel",
                                    "achieved": hb.frames.nbytes / fm / 1e9, "peak": peak,
                                    "unit": "GB/s", "frac": hb.frames.nbytes / fm / 1e9 / peak,

@@ -103,6 +103,8 @@ struct ctr_handle {
   size_t smem_bytes[2][2][MAXNT];
   int block_threads[2][2][MAXNT];
   bool attr_set[2][2][MAXNT] = {};
+  kernel_fn nt1_w2[2][2];         // NT = 1 on 2 wavefronts (CTR_FLAG_THROUGHPUT)
+  bool nt1_w2_attr[2][2] = {};
   small_fn small_table[2][2][2];  // [ndim-2][iso][nf-1]; singles with 16 lanes per cluster
   small_fn small_wide1[2][2];     // singles with 64 lanes per cluster (large windows)
   small_fn small_bulk2[2][2];     // pairs with 16 lanes per cluster (the bulk of a pairs bin)
@@ -267,6 +269,10 @@ int ctr_create(ctr_handle** out, int device) {
   h->small_table[1][1][1] = refine_small_kernel<3, 2, true, 64>;
   h->small_table[1][0][0] = refine_small_kernel<3, 1, false, 16>;
   h->small_table[1][0][1] = refine_small_kernel<3, 2, false, 64>;
+  h->nt1_w2[0][1] = refine_block_kernel<2, true, 1, 2>;
+  h->nt1_w2[0][0] = refine_block_kernel<2, false, 1, 2>;
+  h->nt1_w2[1][1] = refine_block_kernel<3, true, 1, 2>;
+  h->nt1_w2[1][0] = refine_block_kernel<3, false, 1, 2>;
   fill_table<2, true>(h->table[0][1], h->smem_bytes[0][1], h->block_threads[0][1]);
   fill_table<2, false>(h->table[0][0], h->smem_bytes[0][0], h->block_threads[0][0]);
   fill_table<3, true>(h->table[1][1], h->smem_bytes[1][1], h->block_threads[1][1]);
@@ -449,6 +455,18 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     }
     k.order = ord + plan->bin_begin[bin];
     k.n_bin = (int32_t)cnt;
+    if (bin == 0 && (p.flags & CTR_FLAG_THROUGHPUT) != 0) {
+      // 3-4 features on 2 wavefronts instead of 8: a quarter of the LDS and of the wave
+      // slots per cluster, a longer iteration (+13 % fits/s with four batches in flight)
+      kernel_fn f2 = h->nt1_w2[di][ii];
+      constexpr size_t bytes2 = SmemB<1, 2>::bytes;
+      if (!h->nt1_w2_attr[di][ii]) {
+        HIP_TRY(h, hipFuncSetAttribute((const void*)f2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes2));
+        h->nt1_w2_attr[di][ii] = true;
+      }
+      hipLaunchKernelGGL(f2, dim3((unsigned)cnt), dim3(WAVE * 2), bytes2, pick_stream(false), k);
+      continue;
+    }
     hipLaunchKernelGGL(fn, dim3((unsigned)cnt), dim3((unsigned)h->block_threads[di][ii][bin]), bytes, pick_stream(false), k);
   }
   if (plan->bin_count[BIN_TOO_LARGE] > 0) {
