@@ -74,6 +74,7 @@ std::mutex g_mutex;
 // bins: 0..MAXNT-1 generic kernel by NT-1; MAXNT = too large for the engine;
 // MAXNT+1 / MAXNT+2 = singles / pairs with default modes (small kernel)
 constexpr int BIN_TOO_LARGE = MAXNT, BIN_SMALL1 = MAXNT + 1, BIN_SMALL2 = MAXNT + 2, NBINS = MAXNT + 3;
+static_assert(NBINS <= 16, "FrontArgs (aux_kernels.h) holds 16 bins");
 constexpr int NSIDE = 4;  // side streams for concurrent bin launches
 constexpr int GATE_US = 20;  // head start of the block kernels over the small kernels (delay_kernel)
 

@@ -1,3 +1,5 @@
+# Collects what profiles/ holds for a build (run on the GPU box: gpurun -- bash tools/profile_all.sh):
+# bench line, rocprofv3 kernel stats, FETCH_SIZE / WRITE_SIZE passes, cfg5 and cfg3 lines -> gpurun_out/v5_*
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
