@@ -30,8 +30,8 @@ import numpy as np  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--frames', type=int, default=256, help='frames per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg3', 'cfg5'],
@@ -42,7 +42,7 @@ def parse():
                          "the N > 1 code path on a one-GPU box)")
     ap.add_argument('--features', type=int, default=None,
                     help="features per frame/stack (default: the workload's own)")
-    ap.add_argument('--in-flight', type=int, default=4,
+    ap.add_argument('--in-flight', type=int, default=8,
                     help="batches in flight per GPU: step k starts while the slowest clusters of "
                          "steps k-1.. are still being fitted (one engine handle and one set of "
                          "output buffers per batch in flight)")
@@ -78,9 +78,10 @@ def main():
     # handle), and --in-flight batches are in flight: that needs more hardware queues than
     # ROCm's default of 4 per process, or kernels of different streams queue up behind each
     # other.  Read by the HIP runtime when it initialises, hence set before torch is imported.
-    # (Not more than needed: from 24 queues on, every small kernel of the chain -- fill,
-    # frame maximum, ordering -- takes ~0.1 ms instead of ~0.02 ms on this runtime.)
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', str(max(4, 5 * max(1, args.in_flight))))
+    # (At most 20: from 24 queues on, every small kernel of the chain -- fill, frame maximum,
+    # ordering -- takes ~0.1 ms instead of ~0.02 ms on this runtime; with 8 batches in flight
+    # on 20 queues the handles share queues, which costs nothing measurable.)
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', str(min(20, max(4, 5 * max(1, args.in_flight)))))
     import torch
     import torch.distributed as dist
     import clustertracking_amd as cta
@@ -197,6 +198,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # set-up, not a step: the first call of a handle sets kernel attributes and loads code
+    for d in dbs:
+        d.engine.refine_batch_device(d.plan, d.struct, 0)
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()

@@ -1,2 +1,2 @@
-for q in 8 12 16 20 24 32 48; do for sh in 0 3; do GPU_MAX_HW_QUEUES=$q python bench.py --steps 24 --warmup 8 --shard $sh --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('queues $q shard $sh', round(d['value']/1e6,2), round(d['ms_per_step'],3), round(d['roofline_frame_max']['kernel_ms'],4), round(d['roofline']['kernel_ms_one_batch_alone'],3))"; done; done
+for nfl in 8 12; do for sh in 0 1 2 3 4 5 6 7; do GPU_MAX_HW_QUEUES=20 python bench.py --steps 48 --warmup 12 --shard $sh --in-flight $nfl --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('in flight $nfl shard $sh', round(d['value']/1e6,2), round(d['ms_per_step'],3), d['in_flight_results_identical'])"; done; done
