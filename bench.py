@@ -46,6 +46,8 @@ def parse():
                     help="batches in flight per GPU: step k starts while the slowest clusters of "
                          "steps k-1.. are still being fitted (one engine handle and one set of "
                          "output buffers per batch in flight)")
+    ap.add_argument('--rehearse-collectives', action='store_true',
+                    help="run the N > 1 code path (process group, staging, asynchronous gather) with one rank")
     ap.add_argument('--shard', type=int, default=None,
                     help="rehearsal on one GPU: take the frames rank SHARD of a multi-GPU run would get")
     ap.add_argument('--single-device', action='store_true',
@@ -81,7 +83,9 @@ def main():
     # (At most 20: from 24 queues on, every small kernel of the chain -- fill, frame maximum,
     # ordering -- takes ~0.1 ms instead of ~0.02 ms on this runtime; with 8 batches in flight
     # on 20 queues the handles share queues, which costs nothing measurable.)
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', str(min(20, max(4, 5 * max(1, args.in_flight)))))
+    with_collectives = int(os.environ.get('WORLD_SIZE', '1')) > 1 or args.rehearse_collectives
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', str(min(23 if with_collectives else 20,   # RCCL takes a few
+                                                       max(4, 5 * max(1, args.in_flight)))))
     import torch
     import torch.distributed as dist
     import clustertracking_amd as cta
@@ -96,10 +100,12 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if args.single_device:
         local_rank = 0
+    multi = world > 1 or args.rehearse_collectives   # the exchange code path is active
     torch.cuda.set_device(local_rank)
     coll_dev = 'cuda' if args.backend == 'nccl' else 'cpu'   # where collective buffers live
-    if world > 1:
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world,
                                     device_id=torch.device('cuda', local_rank))
@@ -144,57 +150,47 @@ def main():
     # engines; an engine's own stream keeps its steps in order, different engines overlap
     # on the GPU, so the slowest clusters of one step (a bin lasts as long as its slowest
     # cluster) no longer hold up the next steps.
-    # The only exchange of the path: the result rows of every rank go to rank 0.  The rows of
-    # a step are staged and gathered on a stream of their own per engine, behind that step
-    # only; a staging buffer is reused when the gather that read it has completed.
-    send, gather_buf, pending, tstreams, step_no = [], [], [None] * nfl, [], [0]
-    if world > 1:
+    # The only exchange of the path (north_star: RCCL only for the final gather): when the K
+    # steps of the job are done, the result rows of every rank go to rank 0 -- one gather,
+    # inside the timed region.  (A gather per step was tried: with batches in flight every
+    # stream that sits in a device-side wait for a slow step blocks the streams sharing its
+    # hardware queue, and issuing the gathers from the host in step order stalls the host
+    # behind the slowest step; 15-30 % of the throughput either way.)
+    step_no = [0]
+    send, gather_buf = None, None
+    if multi:
         counts = [torch.zeros(1, dtype=torch.int64, device=coll_dev) for _ in range(world)]
         dist.all_gather(counts, torch.tensor([n_feat], dtype=torch.int64, device=coll_dev))
         counts = [int(c.item()) for c in counts]
         width = prep.batch.params.shape[1] + 1
         pad = max(counts)
-        send = [torch.zeros((pad, width), dtype=torch.float64, device=coll_dev) for _ in range(nfl)]
-        gather_buf = [[torch.empty((pad, width), dtype=torch.float64, device=coll_dev)
-                       for _ in range(world)] if rank == 0 else None for _ in range(nfl)]
-        tstreams = [torch.cuda.Stream(db.device) for _ in range(nfl)]
+        send = torch.zeros((pad, width), dtype=torch.float64, device=coll_dev)
+        if rank == 0:
+            gather_buf = [torch.empty((pad, width), dtype=torch.float64, device=coll_dev)
+                          for _ in range(world)]
         # cluster of every feature row, resident on the device: cost[row_cluster] = cost per row
         row_cluster = torch.from_numpy(np.repeat(np.arange(n_fits, dtype=np.int64),
                                                  np.diff(prep.batch.feat_offset))).to(db.device)
 
     def step():
-        k = step_no[0] % nfl
+        d = dbs[step_no[0] % nfl]
         step_no[0] += 1
-        d = dbs[k]
-        if world == 1:
-            d.engine.refine_batch_device(d.plan, d.struct, 0)   # the engine's own stream
-            return
-        ts = tstreams[k]
-        with torch.cuda.stream(ts):
-            if pending[k] is not None:
-                pending[k].wait()                       # the gather that read send[k] is done
-        d.engine.engine_wait_stream(ts.cuda_stream)     # ... and the staging that read params_out
-        d.engine.refine_batch_device(d.plan, d.struct, 0)
-        d.engine.stream_wait_engine(ts.cuda_stream)     # staging starts when this step is done
-        with torch.cuda.stream(ts):
-            buf = send[k]
-            if coll_dev == 'cuda':      # device-to-device, no host sync
-                buf[:n_feat, :width - 1].copy_(d.t['params_out'])
-                buf[:n_feat, width - 1].copy_(d.t['cost'][row_cluster])
-            else:                       # gloo (rehearsal on one box): through host memory
-                buf[:n_feat, :width - 1].copy_(d.t['params_out'].cpu())
-                buf[:n_feat, width - 1].copy_(d.t['cost'][row_cluster].cpu())
-            pending[k] = dist.gather(buf, gather_buf[k], dst=0, async_op=True)
+        d.engine.refine_batch_device(d.plan, d.struct, 0)   # the engine's own stream
+
+    def final_gather():
+        d = dbs[(step_no[0] - 1) % nfl]                 # the batch of the last step
+        d.engine.stream_wait_engine(0)                  # torch's stream waits for that engine
+        if coll_dev == 'cuda':
+            send[:n_feat, :width - 1].copy_(d.t['params_out'])
+            send[:n_feat, width - 1].copy_(d.t['cost'][row_cluster])
+        else:                                           # gloo (rehearsal): through host memory
+            send[:n_feat, :width - 1].copy_(d.t['params_out'].cpu())
+            send[:n_feat, width - 1].copy_(d.t['cost'][row_cluster].cpu())
+        dist.gather(send, gather_buf, dst=0)
 
     def fence():
-        if world > 1:
-            for k in range(nfl):
-                if pending[k] is not None:
-                    with torch.cuda.stream(tstreams[k]):
-                        pending[k].wait()
-                    pending[k] = None
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -204,11 +200,15 @@ def main():
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
+    if multi:
+        final_gather()      # (the first gather sets up the point-to-point channels)
     fence()
     fm_ms, rf_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if multi:
+        final_gather()
     fence()
     elapsed = time.perf_counter() - t0
     # kernel durations of ONE batch running alone, default scheduling (no throughput flag):
@@ -229,22 +229,18 @@ def main():
     copies_same = all(bool(torch.equal(db.t['params_out'], d.t['params_out'])) and
                       bool(torch.equal(db.t['status'], d.t['status'])) for d in dbs[1:ran])
     gather_ok = None
-    if world > 1 and rank == 0:
+    if multi and rank == 0:
         # what arrived in the last gather: rank 0's own rows must be its results, every other
         # rank's rows finite positions inside its frames
-        last = (step_no[0] - 1) % nfl
-        own = gather_buf[last][0][:n_feat, :width - 1].to(db.device)
+        own = gather_buf[0][:n_feat, :width - 1].to(db.device)
         gather_ok = bool(torch.equal(own, db.t['params_out']))
-        if not gather_ok and os.environ.get('CTR_BENCH_DEBUG'):
-            d = (own != db.t['params_out'])
-            sys.stderr.write('gather debug: %d differing elements of %d; rows %s; nan own %d; max |d| %.3e; cols %s\n' % (int(d.sum()), d.numel(), d.any(1).nonzero()[:5].flatten().tolist(), int(torch.isnan(own).sum()), float((own - db.t['params_out']).abs().max()), d.any(0).tolist()))
         for r in range(1, world):
-            rows = gather_buf[last][r][:counts[r], 2:4]
+            rows = gather_buf[r][:counts[r], 2:4]
             gather_ok = gather_ok and bool(torch.isfinite(rows).all()) and bool((rows > -20).all())
 
     t_all = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
     fits_all = torch.tensor([float(n_fits)], dtype=torch.float64, device=coll_dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
         dist.all_reduce(fits_all, op=dist.ReduceOp.SUM)
     elapsed = float(t_all.item())
@@ -347,7 +343,7 @@ def main():
                 "sample": "the full workload of one GPU (%d cluster-fits): oracle/ctr_oracle.c = "
                           "the engine's bounded LM in scalar C, OpenMP over clusters" % n_fits}
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
