@@ -45,25 +45,29 @@ typedef void (*small_fn)(const KArgs, int*);
 
 template <int NT> struct WavesFor { static constexpr int value = NT <= 2 ? 8 : (NT <= 3 ? 4 : (NT <= 6 ? 2 : 1)); };
 
-template <int ND, bool ISO, int NT>
+// CTR_FLAG_THROUGHPUT: fewest wavefronts per cluster (a quarter of the LDS and of the wave slots
+// for 3-4 features; two or three workgroups per CU instead of one for 5-30 features)
+template <int NT> struct WavesThroughput { static constexpr int value = NT <= 2 ? 2 : 1; };
+
+template <int ND, bool ISO, int NT, bool TP = false>
 void fill_one(kernel_fn* t, size_t* bytes, int* threads) {
-  constexpr int W = WavesFor<NT>::value;
+  constexpr int W = TP ? WavesThroughput<NT>::value : WavesFor<NT>::value;
   static_assert(SmemB<NT, W>::bytes <= LDS_CU, "LDS budget of one CU");
   t[NT - 1] = refine_block_kernel<ND, ISO, NT, W>;
   bytes[NT - 1] = SmemB<NT, W>::bytes;
   threads[NT - 1] = WAVE * W;
 }
 
-template <int ND, bool ISO>
+template <int ND, bool ISO, bool TP = false>
 void fill_table(kernel_fn* t, size_t* bytes, int* threads) {
-  fill_one<ND, ISO, 1>(t, bytes, threads);
-  fill_one<ND, ISO, 2>(t, bytes, threads);
-  fill_one<ND, ISO, 3>(t, bytes, threads);
-  fill_one<ND, ISO, 4>(t, bytes, threads);
-  fill_one<ND, ISO, 5>(t, bytes, threads);
-  fill_one<ND, ISO, 6>(t, bytes, threads);
-  fill_one<ND, ISO, 7>(t, bytes, threads);
-  fill_one<ND, ISO, 8>(t, bytes, threads);
+  fill_one<ND, ISO, 1, TP>(t, bytes, threads);
+  fill_one<ND, ISO, 2, TP>(t, bytes, threads);
+  fill_one<ND, ISO, 3, TP>(t, bytes, threads);
+  fill_one<ND, ISO, 4, TP>(t, bytes, threads);
+  fill_one<ND, ISO, 5, TP>(t, bytes, threads);
+  fill_one<ND, ISO, 6, TP>(t, bytes, threads);
+  fill_one<ND, ISO, 7, TP>(t, bytes, threads);
+  fill_one<ND, ISO, 8, TP>(t, bytes, threads);
 }
 
 std::string g_create_error;
@@ -104,8 +108,10 @@ struct ctr_handle {
   size_t smem_bytes[2][2][MAXNT];
   int block_threads[2][2][MAXNT];
   bool attr_set[2][2][MAXNT] = {};
-  kernel_fn nt1_w2[2][2];         // NT = 1 on 2 wavefronts (CTR_FLAG_THROUGHPUT)
-  bool nt1_w2_attr[2][2] = {};
+  kernel_fn table_tp[2][2][MAXNT];   // the same for CTR_FLAG_THROUGHPUT (fewest wavefronts)
+  size_t smem_bytes_tp[2][2][MAXNT];
+  int block_threads_tp[2][2][MAXNT];
+  bool attr_set_tp[2][2][MAXNT] = {};
   small_fn small_table[2][2][2];  // [ndim-2][iso][nf-1]; singles with 16 lanes per cluster
   small_fn small_wide1[2][2];     // singles with 64 lanes per cluster (large windows)
   small_fn small_bulk2[2][2];     // pairs with 16 lanes per cluster (the bulk of a pairs bin)
@@ -270,10 +276,8 @@ int ctr_create(ctr_handle** out, int device) {
   h->small_table[1][1][1] = refine_small_kernel<3, 2, true, 64>;
   h->small_table[1][0][0] = refine_small_kernel<3, 1, false, 16>;
   h->small_table[1][0][1] = refine_small_kernel<3, 2, false, 64>;
-  h->nt1_w2[0][1] = refine_block_kernel<2, true, 1, 2>;
-  h->nt1_w2[0][0] = refine_block_kernel<2, false, 1, 2>;
-  h->nt1_w2[1][1] = refine_block_kernel<3, true, 1, 2>;
-  h->nt1_w2[1][0] = refine_block_kernel<3, false, 1, 2>;
+  fill_table<2, true, true>(h->table_tp[0][1], h->smem_bytes_tp[0][1], h->block_threads_tp[0][1]);
+  fill_table<2, false, true>(h->table_tp[0][0], h->smem_bytes_tp[0][0], h->block_threads_tp[0][0]);
   fill_table<2, true>(h->table[0][1], h->smem_bytes[0][1], h->block_threads[0][1]);
   fill_table<2, false>(h->table[0][0], h->smem_bytes[0][0], h->block_threads[0][0]);
   fill_table<3, true>(h->table[1][1], h->smem_bytes[1][1], h->block_threads[1][1]);
@@ -448,27 +452,19 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
   for (int bin = MAXNT - 1; bin >= 0; --bin) {
     const int64_t cnt = plan->bin_count[bin];
     if (cnt == 0) continue;
-    kernel_fn fn = h->table[di][ii][bin];
-    const size_t bytes = h->smem_bytes[di][ii][bin];
-    if (!h->attr_set[di][ii][bin]) {
+    // (2D only: a 3D window has thousands of pixels, more wavefronts per cluster pay there)
+    const bool tp = (p.flags & CTR_FLAG_THROUGHPUT) != 0 && p.ndim == 2;
+    kernel_fn fn = tp ? h->table_tp[di][ii][bin] : h->table[di][ii][bin];
+    const size_t bytes = tp ? h->smem_bytes_tp[di][ii][bin] : h->smem_bytes[di][ii][bin];
+    const int threads = tp ? h->block_threads_tp[di][ii][bin] : h->block_threads[di][ii][bin];
+    bool& attr = tp ? h->attr_set_tp[di][ii][bin] : h->attr_set[di][ii][bin];
+    if (!attr) {
       HIP_TRY(h, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-      h->attr_set[di][ii][bin] = true;
+      attr = true;
     }
     k.order = ord + plan->bin_begin[bin];
     k.n_bin = (int32_t)cnt;
-    if (bin == 0 && (p.flags & CTR_FLAG_THROUGHPUT) != 0) {
-      // 3-4 features on 2 wavefronts instead of 8: a quarter of the LDS and of the wave
-      // slots per cluster, a longer iteration (+13 % fits/s with four batches in flight)
-      kernel_fn f2 = h->nt1_w2[di][ii];
-      constexpr size_t bytes2 = SmemB<1, 2>::bytes;
-      if (!h->nt1_w2_attr[di][ii]) {
-        HIP_TRY(h, hipFuncSetAttribute((const void*)f2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes2));
-        h->nt1_w2_attr[di][ii] = true;
-      }
-      hipLaunchKernelGGL(f2, dim3((unsigned)cnt), dim3(WAVE * 2), bytes2, pick_stream(false), k);
-      continue;
-    }
-    hipLaunchKernelGGL(fn, dim3((unsigned)cnt), dim3((unsigned)h->block_threads[di][ii][bin]), bytes, pick_stream(false), k);
+    hipLaunchKernelGGL(fn, dim3((unsigned)cnt), dim3((unsigned)threads), bytes, pick_stream(false), k);
   }
   if (plan->bin_count[BIN_TOO_LARGE] > 0) {
     const int64_t cnt = plan->bin_count[BIN_TOO_LARGE];

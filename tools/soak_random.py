@@ -20,6 +20,8 @@ worst = 0.
 for seed in range(first, first + n_seeds):
     f0, im, diameter, kw = _cases.random_case(seed)
     prep = cta.prepare_batch(f0, im, diameter, **kw)
+    if os.environ.get('SOAK_THROUGHPUT'):
+        prep.problem.flags |= _abi.FLAG_THROUGHPUT   # scheduling flag: same results expected
     b = prep.batch
     ref = _abi.HostBatch(b.frames, b.frame_index, b.feat_offset, b.params, b.low, b.high)
     eng.refine_batch(prep.problem, b)
