@@ -18,9 +18,15 @@
 // Variable order (fitfunc.py:207-263): [bg, s_0.., pos(axis 0)_0.., pos(axis 1)_0.., ...].
 
 
-// all-reduce inside a group of SG lanes (16 = one DPP row, 64 = the whole wave)
+// all-reduce inside a group of SG lanes (8 = half a DPP row, 16 = one row, 64 = the whole wave)
 template <int SG>
 __device__ __forceinline__ double group_sum(double x) {
+  if (SG == 8) {
+    x += dpp_f64<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += dpp_f64<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += dpp_f64<0x141>(x);  // row_half_mirror: the other quad of the same eight lanes
+    return x;
+  }
   x = row_sum(x);
   if (SG == 64) {
     x += __shfl_xor(x, 16);
