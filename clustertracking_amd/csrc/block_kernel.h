@@ -1136,6 +1136,13 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             const bool feasible = (m == 0) || (cn <= 1e-10);
             converged = feasible && ((last_acc && stepmax <= xtol) || fabs(pred) <= tiny);
             next = BP_EVAL_TRIAL;
+            if (!converged && m == 0 && !(pred > 0.)) {
+              // the model itself predicts no decrease: rejected without a pixel pass (with
+              // constraints the trial's violation still steers tau, so those are evaluated)
+              mu *= nu; nu *= 2.; last_acc = false;
+              if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+              next = BP_STEP_ONLY;
+            }
           }
         }
       }

@@ -479,6 +479,12 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
           } else {
             converged = (last_acc && stepmax <= xtol) || fabs(pred) <= tiny;
             phase = PH_EVAL_TRIAL;
+            if (!converged && !(pred > 0.)) {
+              // the model itself predicts no decrease: rejected without a pixel pass
+              mu *= nu; nu *= 2.; last_acc = false;
+              if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+              phase = PH_STEP_ONLY;
+            }
           }
         }
       }

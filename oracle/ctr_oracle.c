@@ -580,6 +580,15 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
       out.ok = 1;
       break;
     }
+    if (m == 0 && !(pred > 0.)) {
+      /* the model itself predicts no decrease (projection): rejected without looking at the
+       * pixels -- the test below would reject it whatever the trial gave */
+      mu *= nu;
+      nu *= 2.;
+      last_accepted = 0;
+      if (mu > 1e30) break;
+      continue;
+    }
     eval_cluster(c, vt, &St, gt, At, newton ? Qt : NULL, &P);
     eval_constraints(c, vt, cvt, Cjt, pair_of_t);
     const double cnt = l1norm(cvt, m);
