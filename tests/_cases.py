@@ -86,7 +86,7 @@ def compare(res, ref, pos_columns):
 
 def random_case(seed):
     """A random configuration (dimension, dtype, modes, bounds, constraints, separation) from a
-    seed: the soak tests, tools/check_vs_reference.py and the `hard_*` fixtures share it."""
+    seed: the soak tests, tests/tools/check_vs_reference.py and the `hard_*` fixtures share it."""
     rng = np.random.RandomState(seed)
     ndim = int(rng.choice([2, 3], p=[0.7, 0.3]))
     iso = bool(rng.rand() < 0.5)

@@ -1,12 +1,12 @@
 """The solver's model Hessian and its stopping rules, on the CPU oracle (the engine runs the
-same sequence: tools/iter_parity.py shows equal iteration counts cluster by cluster, and
+same sequence: tests/tools/iter_parity.py shows equal iteration counts cluster by cluster, and
 tests/test_gpu_parity.py compares the results).
 
 The reference leaves the optimisation to SciPy's SLSQP (refine.py:373-375); the engine's
 bounded Levenberg-Marquardt loop is its own, so these tests pin its pieces:
   * the exact second-order part of the model Hessian against finite differences of the
     gradient that the reference's known answers already pin (tests/test_golden_oracle.py);
-  * regressions of the two stopping-rule faults found with tools/check_vs_reference.py.
+  * regressions of the two stopping-rule faults found with tests/tools/check_vs_reference.py.
 """
 import numpy as np
 import pytest

@@ -1,14 +1,14 @@
 """Run every golden fixture through a backend and print the parity table.
 
-    python tools/check_fixtures.py engine     # HIP engine (needs the MI355X)
-    python tools/check_fixtures.py oracle     # C oracle (CPU)
+    python tests/tools/check_fixtures.py engine     # HIP engine (needs the MI355X)
+    python tests/tools/check_fixtures.py oracle     # C oracle (CPU)
 """
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import _cases  # noqa: E402
 
 

@@ -2,7 +2,7 @@
 (oracle/refshim.py, converged: tol=1e-14) and through the C oracle; prints the differences.
 Complements the committed golden fixtures with inputs nobody looked at."""
 import os, sys, warnings
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')
 for p in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'oracle')):
     sys.path.insert(0, p)
 import numpy as np

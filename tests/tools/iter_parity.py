@@ -2,14 +2,14 @@
 re-window rounds and parameters.  Equal iteration counts mean the two implementations
 walk the same path, not only that they end in the same minimum.
 
-    python tools/iter_parity.py [frames] [workload]      # needs the MI355X
+    python tests/tools/iter_parity.py [frames] [workload]      # needs the MI355X
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')
 for p in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'oracle')):
     sys.path.insert(0, p)
 import clustertracking_amd as cta  # noqa: E402

@@ -1,7 +1,7 @@
 """Soak test: many random configurations, engine vs C oracle (tests/test_gpu_parity.py's
-generator with more seeds).   python tools/soak_random.py [n_seeds] [first_seed]"""
+generator with more seeds).   python tests/tools/soak_random.py [n_seeds] [first_seed]"""
 import os, sys
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')
 for p in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'oracle')):
     sys.path.insert(0, p)
 import numpy as np

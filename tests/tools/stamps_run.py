@@ -1,9 +1,9 @@
 """Diagnostic: cycle shares of the block kernel's sections (needs the -DCTR_STAMPS build).
-    CTREFINE_LIB=tools/_stamps/libctrefine_stamps.so python tools/stamps_run.py [min_n] [max_n]
+    CTREFINE_LIB=tools/_stamps/libctrefine_stamps.so python tests/tools/stamps_run.py [min_n] [max_n]
 """
 import ctypes, os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import clustertracking_amd as cta
 from clustertracking_amd import workloads, _abi, _lib
 
@@ -23,7 +23,7 @@ hb = prep.batch
 sz = np.diff(hb.feat_offset)
 sel = np.flatnonzero((sz >= lo_n) & (sz <= hi_n))
 if len(sys.argv) > 3:   # only the slow clusters: every block alone on its CU
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'oracle'))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..', 'oracle'))
     import ctr_oracle
     ctr_oracle.run_batch(prep.problem, hb, 16)
     sel = np.flatnonzero((sz >= lo_n) & (sz <= hi_n) & (hb.n_iter >= int(sys.argv[3])))
