@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_NDIM = 3
 MAX_PARAMS = 8
 MAX_VARS = 127
@@ -61,7 +61,7 @@ class Batch(C.Structure):
         ('frame_index', C.c_void_p), ('feat_offset', C.c_void_p),
         ('params', C.c_void_p), ('low', C.c_void_p), ('high', C.c_void_p),
         ('params_out', C.c_void_p), ('cost', C.c_void_p), ('status', C.c_void_p),
-        ('n_rounds', C.c_void_p), ('n_iter', C.c_void_p),
+        ('n_rounds', C.c_void_p), ('n_iter', C.c_void_p), ('params_std', C.c_void_p),
     ]
 
 
@@ -98,7 +98,7 @@ def make_problem(ndim, isotropic, modes, radius, constraint=None, max_iter=10,
 class HostBatch(object):
     """NumPy-owned buffers of one batch + the ``ctr_batch`` view onto them."""
 
-    def __init__(self, frames, frame_index, feat_offset, params, low, high):
+    def __init__(self, frames, frame_index, feat_offset, params, low, high, want_std=False):
         frames = np.asarray(frames)
         if frames.dtype not in DTYPE_CODES:
             # every other pixel type is widened to f64 exactly like
@@ -128,6 +128,8 @@ class HostBatch(object):
         self.status = np.zeros(n_cl, dtype=np.int32)
         self.n_rounds = np.zeros(n_cl, dtype=np.int32)
         self.n_iter = np.zeros(n_cl, dtype=np.int32)
+        # refine.py:400-406 (compute_error): one standard deviation per fitted parameter
+        self.params_std = np.full_like(self.params, np.nan) if want_std else None
 
     @property
     def n_clusters(self):
@@ -149,4 +151,5 @@ class HostBatch(object):
         for name in ('frame_index', 'feat_offset', 'params', 'low', 'high',
                      'params_out', 'cost', 'status', 'n_rounds', 'n_iter'):
             setattr(b, name, getattr(self, name).ctypes.data)
+        b.params_std = self.params_std.ctypes.data if self.params_std is not None else None
         return b

@@ -80,7 +80,10 @@ __global__ void mark_kernel(const KArgs k, int code) {
   if (t >= k.n_bin) return;
   const int cl = k.order[t];
   const int np = k.prob.n_params;
-  for (int e = k.feat_offset[cl] * np; e < k.feat_offset[cl + 1] * np; ++e) k.params_out[e] = k.params[e];
+  for (int e = k.feat_offset[cl] * np; e < k.feat_offset[cl + 1] * np; ++e) {
+    k.params_out[e] = k.params[e];
+    if (k.params_std) k.params_std[e] = NAN;
+  }
   k.status[cl] = code;
   k.cost[cl] = NAN;
   k.n_rounds[cl] = 0;

@@ -1194,6 +1194,48 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
     const bool ok = status == CTR_STATUS_OK;
     if (ok)
       for (int e = lane; e < n * NP; e += WAVE) pout[e] = cur[(e / NP) * CTR_MAX_PARAMS + (e % NP)];
+    if (k.params_std != nullptr) {
+      // refine.py:400-406: std = sqrt(2 diag(inv(Hessian of F))) at the solution, all variables
+      // free: std_j = sqrt(P norm [(J^T J + Q)^-1]_jj).  Mp and Uc belong to the accepted point v.
+      double* sd = vt;   // (free now)
+      bool pd = ok && n > 0;
+      if (pd) {
+        for (int e = lane; e < tri(nv); e += WAVE) {
+          int a = (int)((sqrt(8. * e + 1.) - 1.) * 0.5);
+          while (tri(a + 1) <= e) ++a;
+          while (tri(a) > e) --a;
+          const int b = e - tri(a);
+          double h = Msym(Mp, a + 1, b + 1);
+          if (newton_on) {
+            const int ia = vinfo[a], ib = vinfo[b];
+            const int ka = (ia & 7) - 1, kb = (ib & 7) - 1;
+            if (ia >= 0 && ((ia ^ ib) >> 3) == 0 && ka >= 0 && kb >= 0 && ka + kb > 0) {
+              const int k0 = ka < kb ? ka : kb, k1 = ka < kb ? kb : ka;
+              const int idx = k0 == 0 ? k1 - 1 : ND + ((k0 - 1) * ND - ((k0 - 1) * (k0 - 2)) / 2 + (k1 - k0));
+              h += Uc[(ia >> 3) * QT + idx];
+            }
+          }
+          Hp[e] = h;
+        }
+        wsync();
+        pd = chol_factor_w(Hp, dl, nv, lane);
+      }
+      if (pd) {
+        const double scale = (double)Pround * norm;
+        for (int j = 0; j < nv; ++j) {
+          for (int i = lane; i < nv; i += WAVE) w[i] = i == j ? 1. : 0.;
+          wsync();
+          chol_solve_w(Hp, dl, nv, w, 1, 0, lane);
+          if (lane == 0) sd[j] = sqrt(scale * w[j]);
+          wsync();
+        }
+      }
+      double* ps = k.params_std + (size_t)f0 * NP;
+      for (int e = lane; e < n * NP; e += WAVE) {
+        const int b = L.vidx(e % NP, e / NP);
+        ps[e] = (pd && b >= 0) ? sd[b] : NAN;
+      }
+    }
     if (lane == 0) {
       k.status[cl] = status;
       k.cost[cl] = ok ? rms : NAN;

@@ -425,6 +425,7 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
   k.status = b->status;
   k.n_rounds = b->n_rounds;
   k.n_iter = b->n_iter;
+  k.params_std = b->params_std;
   k.fmax = h->d_fmax;
   const int di = p.ndim == 3 ? 1 : 0, ii = p.isotropic ? 1 : 0;
   // The bins are independent: the big bin of singles runs on the caller's
@@ -671,7 +672,7 @@ int ctr_refine_batch(ctr_handle* h, const ctr_problem* p, const ctr_batch* b) {
   const size_t sz_fi = al(sizeof(int32_t) * (size_t)C), sz_fo = al(sizeof(int32_t) * (size_t)(C + 1));
   const size_t sz_par = al(sizeof(double) * (size_t)N * np);
   const size_t sz_c = al(sizeof(double) * (size_t)C), sz_ci = al(sizeof(int32_t) * (size_t)C);
-  const size_t total = sz_frames + sz_fi + sz_fo + 4 * sz_par + sz_c + 3 * sz_ci;
+  const size_t total = sz_frames + sz_fi + sz_fo + (b->params_std ? 5 : 4) * sz_par + sz_c + 3 * sz_ci;
   if (total > h->d_buf_bytes) {
     if (h->d_buf) { (void)hipFree(h->d_buf); h->d_buf = nullptr; h->d_buf_bytes = 0; }
     if (hipMalloc(&h->d_buf, total) != hipSuccess) return fail(h, CTR_ERR_NOMEM, "cannot allocate device memory for the batch");
@@ -691,6 +692,7 @@ int ctr_refine_batch(ctr_handle* h, const ctr_problem* p, const ctr_batch* b) {
   int32_t* d_status = (int32_t*)take(sz_ci);
   int32_t* d_rounds = (int32_t*)take(sz_ci);
   int32_t* d_iter = (int32_t*)take(sz_ci);
+  double* d_std = b->params_std ? (double*)take(sz_par) : nullptr;
   hipStream_t s = h->stream;
   HIP_TRY(h, hipMemcpyAsync(d_frames, b->frames, (size_t)b->n_frames * (size_t)frame_elems * isz, hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipMemcpyAsync(d_fi, b->frame_index, sizeof(int32_t) * (size_t)C, hipMemcpyHostToDevice, s));
@@ -701,6 +703,7 @@ int ctr_refine_batch(ctr_handle* h, const ctr_problem* p, const ctr_batch* b) {
   d.frames = d_frames; d.frame_index = d_fi; d.feat_offset = d_fo;
   d.params = d_par; d.low = d_low; d.high = d_high; d.params_out = d_out;
   d.cost = d_cost; d.status = d_status; d.n_rounds = d_rounds; d.n_iter = d_iter;
+  d.params_std = d_std;
   ctr_plan* plan = nullptr;
   rc = ctr_plan_create(h, p, C, b->feat_offset, &plan);
   if (rc) return rc;
@@ -711,6 +714,7 @@ int ctr_refine_batch(ctr_handle* h, const ctr_problem* p, const ctr_batch* b) {
     if (e == hipSuccess) e = hipMemcpyAsync(b->status, d_status, sizeof(int32_t) * (size_t)C, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(b->n_rounds, d_rounds, sizeof(int32_t) * (size_t)C, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(b->n_iter, d_iter, sizeof(int32_t) * (size_t)C, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && d_std) e = hipMemcpyAsync(b->params_std, d_std, sizeof(double) * (size_t)N * np, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) rc = fail(h, CTR_ERR_DEVICE, std::string("copy back / kernel execution: ") + hipGetErrorString(e));
   } else {

@@ -33,6 +33,7 @@ struct KArgs {
   int32_t* status;
   int32_t* n_rounds;
   int32_t* n_iter;
+  double* params_std;    // [N, n_params] or nullptr (ctr_batch.params_std)
   const double* fmax;
   const int32_t* order;  // cluster ids of this bin
   // small kernel only: part of the bin a launch takes.  split == nullptr: all of it;

@@ -541,6 +541,94 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
             }
           }
       }
+      if (k.params_std != nullptr) {
+        // refine.py:400-406: std = sqrt(2 diag(inv(Hessian of F))) at the solution, all variables
+        // free; Hessian of F = 2 (J^T J + Q) / (P norm)  =>  std_j = sqrt(P norm [(J^T J + Q)^-1]_jj).
+        // Mcur holds [J r]^T [J r] and the second-order sums of the accepted point v.
+        double sd[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) sd[j] = NAN;
+        if (ok) {
+          auto Mc = [&](int p2, int c2) -> double {
+            const int a = p2 < c2 ? p2 : c2, b = p2 < c2 ? c2 : p2;
+            return Mcur[a * NR - (a * (a - 1)) / 2 + (b - a)];
+          };
+          double L[NV][NV];
+#pragma unroll
+          for (int p2 = 0; p2 < NV; ++p2)
+#pragma unroll
+            for (int c2 = 0; c2 <= p2; ++c2) L[p2][c2] = Mc(p2, c2);
+#pragma unroll
+          for (int i = 0; i < NF; ++i) {
+            const double sig = v[1 + i], gs = Mc(1 + i, NV);
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              const int ca = 1 + NF + a * NF + i;
+              L[ca][1 + i] += sig != 0. ? Mc(ca, NV) / sig : 0.;
+#pragma unroll
+              for (int b = 0; b <= a; ++b) {
+                double u = Mcur[NM + i * NUF + (b * ND - (b * (b - 1)) / 2 + (a - b))];
+                if (a == b) u -= (double)ND * isz2[i][a] * sig * gs;
+                L[ca][1 + NF + b * NF + i] += u;
+              }
+            }
+          }
+          bool pd = true;
+          double dinv[NV];
+#pragma unroll
+          for (int j = 0; j < NV; ++j) {
+            double d = L[j][j];
+#pragma unroll
+            for (int q2 = 0; q2 < j; ++q2) d -= L[j][q2] * L[j][q2];
+            if (!(d > 0.) || !isfinite(d)) pd = false;
+            const double di = 1. / sqrt(d);
+            dinv[j] = di;
+#pragma unroll
+            for (int i = j + 1; i < NV; ++i) {
+              double t = L[i][j];
+#pragma unroll
+              for (int q2 = 0; q2 < j; ++q2) t -= L[i][q2] * L[j][q2];
+              L[i][j] = t * di;
+            }
+          }
+          if (pd) {
+            // [(L L^T)^-1]_jj = sum_k (L^-1)_kj^2: column j of L^-1 by forward substitution
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+              double y[NV], acc = 0.;
+#pragma unroll
+              for (int kk = 0; kk < NV; ++kk) {
+                double t = kk == j ? 1. : 0.;
+#pragma unroll
+                for (int q2 = 0; q2 < kk; ++q2)
+                  if (q2 >= j) t -= L[kk][q2] * y[q2];
+                y[kk] = kk < j ? 0. : t * dinv[kk];
+                acc += y[kk] * y[kk];
+              }
+              sd[j] = sqrt((double)Pround * norm * acc);
+            }
+          }
+        }
+        double* ps = k.params_std + (size_t)f0 * NP;
+        if (sub < NF) {
+#pragma unroll
+          for (int ii = 0; ii < NF; ++ii)
+            if (ii == sub) {
+#pragma unroll
+              for (int kk = 0; kk < NP; ++kk) {
+                double x = NAN;   // constant parameters (the sizes here) carry no error
+                if (kk == 0) x = sd[0];
+                else if (kk == 1) x = sd[1 + ii];
+                else if (kk < 2 + ND) {
+#pragma unroll
+                  for (int a = 0; a < ND; ++a)
+                    if (kk == 2 + a) x = sd[1 + NF + a * NF + ii];
+                }
+                ps[ii * NP + kk] = x;
+              }
+            }
+        }
+      }
       if (sub == 0) {
         k.status[cl] = status;
         k.cost[cl] = ok ? rms : NAN;

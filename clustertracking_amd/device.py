@@ -37,6 +37,9 @@ class DeviceBatch(object):
                 n_iter=torch.empty(hb.n_clusters, dtype=torch.int32, device=self.device),
             )
             torch.cuda.synchronize(self.device)
+        if hb.params_std is not None:
+            with torch.cuda.device(self.device):
+                self.t['params_std'] = torch.empty(hb.params.shape, dtype=torch.float64, device=self.device)
         b = hb.as_struct()
         for name, tensor in self.t.items():
             setattr(b, name, tensor.data_ptr())
@@ -72,6 +75,8 @@ class DeviceBatch(object):
         hb.status[...] = self.t['status'].cpu().numpy()
         hb.n_rounds[...] = self.t['n_rounds'].cpu().numpy()
         hb.n_iter[...] = self.t['n_iter'].cpu().numpy()
+        if hb.params_std is not None:
+            hb.params_std[...] = self.t['params_std'].cpu().numpy()
         return hb
 
     def results_tensor(self):

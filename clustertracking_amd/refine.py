@@ -66,7 +66,8 @@ def prepare_batch(f, reader, diameter, separation=None, fit_function='gauss',
                   param_mode=None, param_val=None, constraints=None, bounds=None,
                   pos_columns=None, t_column='frame', max_iter=10, max_shift=1,
                   max_rms_dev=1., residual_factor=100000., solver_maxiter=100,
-                  xtol=0., ftol=0., cluster_labels='reference', device=0):
+                  xtol=0., ftol=0., cluster_labels='reference', device=0,
+                  compute_error=False):
     """Host-side set-up of one refine call (reference refine.py:242-341)."""
     if pos_columns is None:
         pos_columns = guess_pos_columns(f)
@@ -92,6 +93,17 @@ def prepare_batch(f, reader, diameter, separation=None, fit_function='gauss',
         raise NotImplementedError("param modes 'particle'/'frame' are not "
                                   "implemented (reference refine.py:339-340)")
     cons = engine_constraint(constraints, ndim)
+    if compute_error:
+        # refine.py:400-406 takes the Hessian of the objective by finite differences; the engine
+        # has its second derivatives w.r.t. signal and positions exactly, none w.r.t. sizes
+        names = ff.params
+        size_modes = [m for nme, m in zip(names, modes) if nme.startswith('size')]
+        pos_modes = [modes[names.index(c)] for c in pos_columns]
+        if any(m != 0 for m in size_modes) or modes[names.index('signal')] != 1 or \
+                any(m != 1 for m in pos_modes):
+            raise NotImplementedError(
+                "compute_error needs constant sizes and per-feature signal and positions "
+                "(the default modes): the engine's Hessian is exact for those only")
 
     f = find_clusters(f, separation, pos_columns, t_column, labels=cluster_labels,
                       device=device)  # makes a copy
@@ -141,7 +153,7 @@ def prepare_batch(f, reader, diameter, separation=None, fit_function='gauss',
                                 residual_factor=residual_factor,
                                 solver_maxiter=solver_maxiter, xtol=xtol, ftol=ftol)
     batch = _abi.HostBatch(frames, frame_index, feat_offset, params[order],
-                           low[order], high[order])
+                           low[order], high[order], want_std=bool(compute_error))
     # SciPy raises ValueError for an infeasible box (lower > upper)
     n_per = np.diff(feat_offset)
     if n_rows:
@@ -169,6 +181,12 @@ def write_back(prep):
     for k, col in enumerate(ff.params):
         f[col] = out[:, k]
     f['cost'] = cost
+    if batch.params_std is not None:      # refine.py:307-312,423-429: '<param>_std' of the fitted ones
+        std = np.empty((n_rows, len(ff.params)), dtype=np.float64)
+        std[prep.order] = batch.params_std
+        for k, col in enumerate(ff.params):
+            if ff.modes[k] > 0:
+                f[col + '_std'] = std[:, k]
     failed = np.flatnonzero(batch.status != _abi.STATUS_OK)
     for c in failed:
         logger.warning('RefineException: ' + _abi.STATUS_TEXT.get(
@@ -205,8 +223,11 @@ def refine_leastsq(f, reader, diameter, separation=None, fit_function='gauss',
       the reference's, labelled on the host; 'device': same partition labelled on
       the GPU, canonical ids).
     * ``fit_function`` other than ``'gauss'``, ``param_mode`` value
-      ``'global'``, ``noise_size`` and ``compute_error`` raise
-      ``NotImplementedError`` (there is no CPU fallback to hand them to).
+      ``'global'`` and ``noise_size`` raise ``NotImplementedError`` (there is no CPU
+      fallback to hand them to).
+    * ``compute_error``: the ``'<param>_std'`` columns come from the exact second
+      derivatives of the objective (the reference differentiates numerically with
+      numdifftools); supported with constant sizes and per-feature signal and positions.
     * A cluster whose coordinates are all outside the frame, or that has
       non-finite parameters, gets ``cost = NaN`` (the reference means to do
       that, but crashes with IndexError at refine.py:417).
@@ -222,9 +243,6 @@ def refine_leastsq(f, reader, diameter, separation=None, fit_function='gauss',
     run_batch = kwargs.pop('_run_batch', None)  # test hook (oracle on CPU)
     if kwargs:
         raise TypeError("unexpected keyword arguments: %s" % sorted(kwargs))
-    if compute_error:
-        raise NotImplementedError("compute_error is not implemented by the "
-                                  "MI355X engine")
     if noise_size is not None:
         raise NotImplementedError("noise_size (lowpass inside the window) is "
                                   "not implemented by the MI355X engine")
@@ -234,7 +252,8 @@ def refine_leastsq(f, reader, diameter, separation=None, fit_function='gauss',
                          pos_columns, t_column, max_iter, max_shift,
                          max_rms_dev, residual_factor,
                          solver_maxiter=int(options.get('maxiter', 100)),
-                         xtol=xtol, ftol=ftol, cluster_labels=cluster_labels, device=device)
+                         xtol=xtol, ftol=ftol, cluster_labels=cluster_labels, device=device,
+                         compute_error=compute_error)
     if prep.batch.n_clusters:
         if run_batch is None:
             _run_on_engine(prep.problem, prep.batch, device)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CTR_ABI_VERSION 1
+#define CTR_ABI_VERSION 2
 #define CTR_MAX_NDIM 3
 #define CTR_MAX_PARAMS 8 /* background, signal, <=3 positions, <=3 sizes */
 #define CTR_MAX_VARS 127 /* optimiser variables per cluster (engine limit) */
@@ -123,6 +123,14 @@ typedef struct ctr_batch {
   int32_t* status;             /* [C] CTR_STATUS_* */
   int32_t* n_rounds;           /* [C] re-window rounds used */
   int32_t* n_iter;             /* [C] solver iterations, summed over rounds */
+  double* params_std;          /* [N, n_params] or NULL.  refine.py:400-406 (compute_error):
+                                  sqrt(2 diag(inv(H))), H = Hessian of the objective at the
+                                  solution over ALL variables of the cluster (bounds and
+                                  constraints ignored, as there); here from the exact second
+                                  derivatives instead of finite differences.  NaN for constant
+                                  parameters, failed clusters and a Hessian that is not positive
+                                  definite.  Exact when the sizes are constant and signal and
+                                  positions per-feature variables (the default modes). */
 } ctr_batch;
 
 typedef struct ctr_handle ctr_handle;

@@ -630,6 +630,33 @@ done:
   return out;
 }
 
+/* refine.py:400-406: std = sqrt(2 diag(inv(Hessian of F))) at the solution, all variables
+ * free.  Hessian of F = 2 (J^T J + Q) / (P norm), so std_i = sqrt(P norm [(J^T J + Q)^-1]_ii).
+ * Returns 0 (and NaNs) when the matrix is not positive definite. */
+static int solution_std(const ctx_t* c, const double* v, double norm, double* std) {
+  const int nv = c->L.nv;
+  double *g = malloc(sizeof(double) * nv), *A = malloc(sizeof(double) * nv * nv);
+  double *Q = calloc((size_t)nv * nv, sizeof(double)), *e = malloc(sizeof(double) * nv);
+  double S;
+  long P;
+  int ok;
+  int newton = use_newton && c->p->modes[1] == CTR_MODE_VAR;
+  for (int a = 0; a < c->L.nd; ++a) newton = newton && c->p->modes[2 + a] == CTR_MODE_VAR;
+  eval_cluster(c, v, &S, g, A, newton ? Q : NULL, &P);
+  for (int i = 0; i < nv * nv; ++i) A[i] += Q[i];
+  ok = cholesky(A, nv, nv);
+  for (int i = 0; i < nv; ++i) {
+    std[i] = NAN;
+    if (!ok) continue;
+    memset(e, 0, sizeof(double) * nv);
+    e[i] = 1.;
+    chol_solve(A, nv, nv, e);
+    std[i] = sqrt((double)P * norm * e[i]);
+  }
+  free(g); free(A); free(Q); free(e);
+  return ok;
+}
+
 /* ---- one cluster (refine.py:343-430) -------------------------------------- */
 
 static void pack_start(const ctx_t* c, const double* params, const double* low,
@@ -668,6 +695,8 @@ static void refine_one(const ctr_problem* p, const ctr_batch* b, int64_t cl,
   ctx_t c;
   size_t felems = 1;
   memcpy(pout, params, sizeof(double) * (size_t)n * np);
+  if (b->params_std)
+    for (int i = 0; i < n * np; ++i) b->params_std[(size_t)f0 * np + i] = NAN;
   b->cost[cl] = NAN;
   b->n_rounds[cl] = 0;
   b->n_iter[cl] = 0;
@@ -681,7 +710,7 @@ static void refine_one(const ctr_problem* p, const ctr_batch* b, int64_t cl,
   c.n_cons = n_constraints(p, n);
   {
     const int nv = c.L.nv;
-    double v0[MAXV], lo[MAXV], hi[MAXV], v[MAXV];
+    double v0[MAXV], lo[MAXV], hi[MAXV], v[MAXV], vstd[MAXV];
     double* cur = malloc(sizeof(double) * (size_t)n * np);   /* params after the latest round */
     double* coords = malloc(sizeof(double) * (size_t)n * nd);
     const double fm = fmax[b->frame_index[cl]];
@@ -705,6 +734,7 @@ static void refine_one(const ctr_problem* p, const ctr_batch* b, int64_t cl,
       if (r.P == 0) { status = CTR_STATUS_OUT_OF_BOUNDS; break; }
       if (!r.ok) { status = CTR_STATUS_NO_CONVERGENCE; break; } /* refine.py:376-377 */
       rms = sqrt(((r.S / (double)r.P) / norm) / p->residual_factor); /* refine.py:379 */
+      if (b->params_std) solution_std(&c, v, norm, vstd); /* refine.py:400-406, this round's masks */
       int moved = 0;
       for (int i = 0; i < n; ++i) {
         double d2 = 0.;
@@ -724,6 +754,12 @@ static void refine_one(const ctr_problem* p, const ctr_batch* b, int64_t cl,
     if (status == CTR_STATUS_OK) {
       memcpy(pout, cur, sizeof(double) * (size_t)n * np);
       b->cost[cl] = rms;
+      if (b->params_std)   /* vect_to_params of the std vector (refine.py:403-406) */
+        for (int i = 0; i < n; ++i)
+          for (int k = 0; k < np; ++k) {
+            int bb = c.L.var_of[k];
+            if (bb >= 0) b->params_std[(size_t)(f0 + i) * np + k] = vstd[bb + (c.L.per_feat[k] ? i : 0)];
+          }
     }
     (void)nv;
     free(cur);

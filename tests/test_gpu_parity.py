@@ -356,3 +356,39 @@ def test_random_configurations_vs_oracle(engine, oracle, block):
             assert d.max() < 1e-3, 'seed %d' % seed
         n_ok += int(ok.sum())
     assert n_ok > 0
+
+
+@pytest.mark.parametrize("name", ['cfg1_triple', 'cfg2_frame_noisy', 'aniso3d_default', 'cfg5_dense'])
+def test_parameter_standard_deviations_engine_vs_oracle(engine, oracle, name):
+    """ctr_batch.params_std (compute_error, refine.py:400-406): the engine's values equal the
+    oracle's (pinned in tests/test_solver_model.py against a finite-difference Hessian)."""
+    case = _cases.Case(name)
+    prep = case.prepare()
+    b0 = prep.batch
+    mk = lambda: _abi.HostBatch(b0.frames, b0.frame_index, b0.feat_offset, b0.params, b0.low,
+                                b0.high, want_std=True)
+    b, ref = mk(), mk()
+    engine.refine_batch(prep.problem, b)
+    oracle.run_batch(prep.problem, ref, 1)
+    assert_equal(b.status, ref.status)
+    assert_equal(np.isnan(b.params_std), np.isnan(ref.params_std))
+    ok = ~np.isnan(ref.params_std)
+    assert ok.any()
+    assert_allclose(b.params_std[ok], ref.params_std[ok], rtol=1e-6)
+    # and without the buffer nothing changes
+    b2 = clone_batch(b0)
+    engine.refine_batch(prep.problem, b2)
+    assert_equal(b2.params_out, b.params_out)
+
+
+def test_compute_error_through_the_host_api(engine):
+    case = _cases.Case('cfg2_frame_noisy')
+    diameter, kw = case.kwargs()
+    res = cta.refine_leastsq(case.f0.copy(), case.reader(), diameter, compute_error=True, **kw)
+    for col in ('background_std', 'signal_std', 'y_std', 'x_std'):
+        assert col in res and np.isfinite(res[col][~np.isnan(res['cost'])]).all()
+    assert 'size_std' not in res          # constant parameter (refine.py:309-311)
+    assert 0.005 < res['x_std'].median() < 0.2     # S/N 10, size 3: a few hundredths of a pixel
+    with pytest.raises(NotImplementedError):
+        cta.refine_leastsq(case.f0.copy(), case.reader(), diameter, compute_error=True,
+                           param_mode={'size': 'var'})

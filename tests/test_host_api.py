@@ -115,7 +115,9 @@ def test_unsupported_is_loud(oracle):
     im, truth, f0 = small_problem()
     run = _cases.oracle_runner()
     for kw in (dict(param_mode=dict(signal='global')), dict(fit_function='ring'),
-               dict(fit_function='disc'), dict(compute_error=True), dict(noise_size=1),
+               dict(fit_function='disc'), dict(noise_size=1),
+               dict(compute_error=True, param_mode=dict(size='var')),   # exact Hessian: sizes const only
+               dict(compute_error=True, param_mode=dict(signal='cluster')),
                dict(fit_function=dict(params=[], func=None))):
         with pytest.raises(NotImplementedError):
             cta.refine_leastsq(f0.copy(), im, 13, _run_batch=run, **kw)
