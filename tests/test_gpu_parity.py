@@ -392,3 +392,24 @@ def test_compute_error_through_the_host_api(engine):
     with pytest.raises(NotImplementedError):
         cta.refine_leastsq(case.f0.copy(), case.reader(), diameter, compute_error=True,
                            param_mode={'size': 'var'})
+
+
+def test_device_path_is_ordered_with_torchs_default_stream(engine, cfg2_full):
+    """DeviceBatch.run() on torch's legacy default stream: the engine works on its own
+    non-blocking stream, ctr_stream_wait_engine orders torch's stream behind it -- a torch
+    operation queued right after run() must see the finished table (without the ordering the
+    multi-rank bench once gathered rows that were still being written)."""
+    import torch
+    from clustertracking_amd.device import DeviceBatch
+    prep, _ = cfg2_full
+    hb = prep.batch
+    db = DeviceBatch(prep.problem, hb, device=0, engine=engine)
+    db.t['params_out'].zero_()
+    torch.cuda.synchronize()
+    db.run()
+    early = db.t['params_out'].clone()      # queued on the default stream, no host sync
+    torch.cuda.synchronize()
+    assert bool(torch.equal(early, db.t['params_out']))
+    ref = clone_batch(hb)
+    engine.refine_batch(prep.problem, ref)
+    assert_equal(early.cpu().numpy(), ref.params_out)
