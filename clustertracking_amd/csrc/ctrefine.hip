@@ -112,10 +112,9 @@ struct ctr_handle {
   size_t smem_bytes_tp[2][2][MAXNT];
   int block_threads_tp[2][2][MAXNT];
   bool attr_set_tp[2][2][MAXNT] = {};
-  small_fn small_table[2][2][2];  // [ndim-2][iso][nf-1]; singles with 16 lanes per cluster
+  small_fn small_table[2][2][2];  // [ndim-2][iso][nf-1]; singles with 8 lanes per cluster (eight per wavefront)
   small_fn small_wide1[2][2];     // singles with 64 lanes per cluster (large windows)
   small_fn small_bulk2[2][2];     // pairs with 16 lanes per cluster (the bulk of a pairs bin)
-  small_fn small_tp1[2][2];       // singles with 8 lanes per cluster (CTR_FLAG_THROUGHPUT, small windows)
   hipStream_t side[NSIDE] = {};
   hipEvent_t ev_fork = nullptr, ev_gate = nullptr, ev_order = nullptr, ev_join[NSIDE] = {};
   int* d_counter = nullptr;       // work counters of the small-kernel launches
@@ -265,21 +264,17 @@ int ctr_create(ctr_handle** out, int device) {
   h->small_wide1[0][0] = refine_small_kernel<2, 1, false, 64>;
   h->small_wide1[1][1] = refine_small_kernel<3, 1, true, 64>;
   h->small_wide1[1][0] = refine_small_kernel<3, 1, false, 64>;
-  h->small_tp1[0][1] = refine_small_kernel<2, 1, true, 8>;
-  h->small_tp1[0][0] = refine_small_kernel<2, 1, false, 8>;
-  h->small_tp1[1][1] = refine_small_kernel<3, 1, true, 8>;
-  h->small_tp1[1][0] = refine_small_kernel<3, 1, false, 8>;
   h->small_bulk2[0][1] = refine_small_kernel<2, 2, true, 16>;
   h->small_bulk2[0][0] = refine_small_kernel<2, 2, false, 16>;
   h->small_bulk2[1][1] = refine_small_kernel<3, 2, true, 16>;
   h->small_bulk2[1][0] = refine_small_kernel<3, 2, false, 16>;
-  h->small_table[0][1][0] = refine_small_kernel<2, 1, true, 16>;
+  h->small_table[0][1][0] = refine_small_kernel<2, 1, true, 8>;
   h->small_table[0][1][1] = refine_small_kernel<2, 2, true, 64>;
-  h->small_table[0][0][0] = refine_small_kernel<2, 1, false, 16>;
+  h->small_table[0][0][0] = refine_small_kernel<2, 1, false, 8>;
   h->small_table[0][0][1] = refine_small_kernel<2, 2, false, 64>;
-  h->small_table[1][1][0] = refine_small_kernel<3, 1, true, 16>;
+  h->small_table[1][1][0] = refine_small_kernel<3, 1, true, 8>;
   h->small_table[1][1][1] = refine_small_kernel<3, 2, true, 64>;
-  h->small_table[1][0][0] = refine_small_kernel<3, 1, false, 16>;
+  h->small_table[1][0][0] = refine_small_kernel<3, 1, false, 8>;
   h->small_table[1][0][1] = refine_small_kernel<3, 2, false, 64>;
   fill_table<2, true, true>(h->table_tp[0][1], h->smem_bytes_tp[0][1], h->block_threads_tp[0][1]);
   fill_table<2, false, true>(h->table_tp[0][0], h->smem_bytes_tp[0][0], h->block_threads_tp[0][0]);
@@ -495,19 +490,14 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     int* counter = h->d_counter + nf;
     k.order = ord + plan->bin_begin[bin];
     k.n_bin = (int32_t)cnt;
-    // lanes per cluster by the size of a single-feature window: 16 (four clusters per
-    // wave) while a window is a few passes, 64 once it is thousands of pixels (3D)
+    // lanes per cluster by the size of a single-feature window: 8 (eight clusters per
+    // wavefront: the solve, replicated in the lanes of a group, is shared by as many) while
+    // a window is a few passes, 64 once it is thousands of pixels (3D)
     int64_t vol = 1;
     for (int a = 0; a < p.ndim; ++a) vol *= 2 * (int64_t)p.radius[a] + 1;
     const bool wide = nf == 2 || vol > 600;
     small_fn fn = nf == 2 ? h->small_table[di][ii][1] : (wide ? h->small_wide1[di][ii] : h->small_table[di][ii][0]);
-    int64_t waves = wide ? cnt : (cnt + 3) / 4;
-    if (nf == 1 && !wide && (p.flags & CTR_FLAG_THROUGHPUT) != 0) {
-      // eight singles per wavefront: the solve is replicated in the lanes of a group, so it is
-      // shared by twice as many clusters; the pixel pass of one cluster takes twice as long
-      fn = h->small_tp1[di][ii];
-      waves = (cnt + 7) / 8;
-    }
+    int64_t waves = wide ? cnt : (cnt + 7) / 8;
     if (nf == 2 && vol <= 600 && cnt >= 64 && (p.flags & CTR_FLAG_THROUGHPUT) != 0) {
       // Pairs in two tiers (CTR_FLAG_THROUGHPUT: +9 % with four batches in flight, but the
       // one-batch-at-a-time step gets 12 % longer).  One wavefront per pair gives the shortest iteration, which is

@@ -37,7 +37,7 @@ __device__ __forceinline__ double group_sum(double x) {
 
 enum { PH_FETCH = 0, PH_EVAL_INIT = 1, PH_EVAL_TRIAL = 2, PH_STEP_ONLY = 3, PH_DONE = 4 };
 
-// SG = lanes per cluster: 16 (four clusters per wave; singles) or 64 (pairs: a
+// SG = lanes per cluster: 8 (eight singles per wave), 16 (four pairs per wave) or 64 (pairs: a
 // quarter of the per-iteration latency, which is what bounds the slowest pair).
 template <int ND, int NF, bool ISO, int SG>
 __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* __restrict__ counter) {

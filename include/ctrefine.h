@@ -64,9 +64,9 @@ enum { CTR_CONS_NONE = 0, CTR_CONS_DIMER = 1, CTR_CONS_TRIMER = 2, CTR_CONS_TETR
 
 /* ctr_problem.flags.  Scheduling only: the results do not depend on them.
  * CTR_FLAG_THROUGHPUT: the caller keeps several batches in flight on one device (one handle
- * each); favour machine time per cluster over the latency of one batch -- singles share a
- * wavefront eight at a time, pairs that are not likely to be slow fits four at a time, larger
- * 2D clusters run on the fewest wavefronts. */
+ * each); favour machine time per cluster over the latency of one batch -- pairs that are not
+ * likely to be slow fits share a wavefront four at a time, larger 2D clusters run on the
+ * fewest wavefronts. */
 enum { CTR_FLAG_THROUGHPUT = 1 };
 
 /* per-cluster status */

@@ -98,8 +98,8 @@ def test_cfg2_full_size_vs_oracle_and_truth(engine, oracle, cfg2_full):
 
 
 def test_cfg2_throughput_flag_changes_scheduling_not_results(engine, oracle, cfg2_full):
-    """CTR_FLAG_THROUGHPUT (include/ctrefine.h): singles eight per wavefront, the pairs that
-    are not likely slow fits four per wavefront, larger clusters on the fewest wavefronts.  Same statuses, iteration counts and
+    """CTR_FLAG_THROUGHPUT (include/ctrefine.h): the pairs that are not likely slow fits four
+    per wavefront, larger clusters on the fewest wavefronts.  Same statuses, iteration counts and
     (to summation order) values as the default scheduling and as the oracle."""
     import copy
     prep, _ = cfg2_full
