@@ -308,6 +308,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
 #pragma unroll
   for (int kk = 2 + ND; kk < NP; ++kk) size_is_var = size_is_var || L.slot[kk] >= 0;
   auto fill_fpar = [&](const double* vv, bool sizes) {
+    bool bad_size = false;
     for (int i = lane; i < n; i += WAVE) {
       double* f = fpar + i * FP;
       f[0] = par(vv, i, 1);
@@ -317,11 +318,16 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         if (sizes) {  // three f64 divisions per axis: only when a size actually changed
           const double sz = par(vv, i, ISO ? 2 + ND : 2 + ND + a);
           const double s2 = sz * sz;
+          bad_size = bad_size || !(sz > 0.);
           f[4 + a] = 1. / s2;
           f[7 + a] = 2. / s2;
           f[10 + a] = -2. / (s2 * sz);
         }
       }
+    }
+    if (sizes) {
+      const bool anyb = __ballot(bad_size) != 0ull;
+      if (lane == 0) ctl[7] = anyb ? 1 : 0;
     }
   };
   // masks.py:42-68 on the mask centres; wave-uniform
@@ -406,6 +412,94 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
     wsync();
   };
 
+  // m x m SPD solve in LDS by lane 0 (m <= 6): Gm[MAXC*MAXC] <- Cholesky factor, rhs solved in
+  // place; flag[0] = 1 on success.  Ends with a wsync.
+  auto small_spd_solve = [&](double* Gm, double* rhs) {
+    if (lane == 0) {
+      double tr = 0.;
+      for (int r = 0; r < m; ++r) tr += Gm[r * MAXC + r];
+      bool okc = tr > 0.;
+      for (int r = 0; r < m; ++r) Gm[r * MAXC + r] += 1e-14 * tr + 1e-300;
+      for (int j = 0; j < m && okc; ++j) {
+        double d = Gm[j * MAXC + j];
+        for (int q = 0; q < j; ++q) d -= Gm[j * MAXC + q] * Gm[j * MAXC + q];
+        if (!(d > 0.) || !isfinite(d)) { okc = false; break; }
+        d = sqrt(d);
+        Gm[j * MAXC + j] = d;
+        for (int i = j + 1; i < m; ++i) {
+          double s2 = Gm[i * MAXC + j];
+          for (int q = 0; q < j; ++q) s2 -= Gm[i * MAXC + q] * Gm[j * MAXC + q];
+          Gm[i * MAXC + j] = s2 / d;
+        }
+      }
+      if (okc) {
+        for (int i = 0; i < m; ++i) {
+          double s2 = rhs[i];
+          for (int q = 0; q < i; ++q) s2 -= Gm[i * MAXC + q] * rhs[q];
+          rhs[i] = s2 / Gm[i * MAXC + i];
+        }
+        for (int i = m - 1; i >= 0; --i) {
+          double s2 = rhs[i];
+          for (int q = i + 1; q < m; ++q) s2 -= Gm[q * MAXC + i] * rhs[q];
+          rhs[i] = s2 / Gm[i * MAXC + i];
+        }
+      }
+      flag[0] = okc ? 1. : 0.;
+    }
+    wsync();
+  };
+  // Retraction onto the constraint manifold c(x) = 0 (oracle retract()): minimum-norm Newton
+  // steps x <- x - C^T (C C^T)^-1 c over the variables the box leaves free, clipped to the
+  // box; a variable on a bound that the correction would push outward is left out.  Wave 0,
+  // one variable per lane (constrained clusters have at most 29 variables).  On success cvo /
+  // Cjo / cpo describe the constraints at the returned point.
+  auto retract = [&](double* x, double* cvo, double* Cjo, int* cpo) -> bool {
+    double* ry = cv + 18;   // (6 free doubles of the small block)
+    for (int iter = 0; iter <= 30; ++iter) {
+      eval_constraints(x, cvo, Cjo, cpo);
+      double cmax = 0.;
+      bool nan = false;
+      for (int r = 0; r < m; ++r) { const double a = fabs(cvo[r]); nan = nan || !(a == a); cmax = fmax(cmax, a); }
+      if (nan) return false;
+      if (cmax <= 1e-13) return true;
+      if (iter == 30) break;
+      const bool isvar = lane < nv;
+      const double xi = isvar ? x[lane] : 0., li = isvar ? lo[lane] : 0., ui = isvar ? hi[lane] : 0.;
+      bool pinned = !isvar || !(li < ui);
+      double ti = 0.;
+      for (int pass = 0; pass < 2; ++pass) {
+        const unsigned long long fm = __ballot(!pinned);
+        if (lane < m * m) {
+          const int r = lane / m, s2 = lane % m;
+          double t = 0.;
+          for (unsigned long long q = fm; q != 0ull; q &= q - 1ull) {
+            const int i = __builtin_ctzll(q);
+            t += Cjo[r * LDC + i] * Cjo[s2 * LDC + i];
+          }
+          Sc[r * MAXC + s2] = t;
+        }
+        if (lane < m) ry[lane] = cvo[lane];
+        wsync();
+        small_spd_solve(Sc, ry);
+        if (flag[0] == 0.) return false;
+        ti = 0.;
+        if (!pinned)
+          for (int r = 0; r < m; ++r) ti += Cjo[r * LDC + lane] * ry[r];
+        if (pass == 1) break;
+        const bool newpin = !pinned && ((xi <= li && ti > 0.) || (xi >= ui && ti < 0.));
+        if (__ballot(newpin) == 0ull) break;
+        pinned = pinned || newpin;
+        wsync();
+      }
+      if (!pinned && ti != 0.) {
+        const double t = xi - ti;
+        x[lane] = t < li ? li : (t > ui ? ui : t);
+      }
+      wsync();
+    }
+    return false;
+  };
+
   // ---- set-up (all threads) ---------------------------------------------------------
   bool finite = true;
   for (int e = tid; e < n * NP; e += WAVE * W) {
@@ -463,7 +557,8 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
   // state of the solver, meaningful in wave 0 (uniform there)
   int status = nonfinite ? CTR_STATUS_NONFINITE : (n <= 0 ? CTR_STATUS_OUT_OF_BOUNDS : CTR_STATUS_OK);
   int round = 0, it = 0, iters = 0, Pround = 0;
-  double mu = 1e-3, nu = 2., sigma = 0., tau = 1., S = 0., pred = 0., cn = 0., cn_pred = 0., rms = NAN;
+  double mu = 1e-3, nu = 2., S = 0., pred = 0., rms = NAN;
+  bool retr_fail = false;   // the start vector could not be brought onto the constraint manifold
   bool last_acc = true;
   double gain = INFINITY;  // relative merit decrease of the last accepted step
   const double fm = k.fmax[k.frame_index[cl]];
@@ -487,6 +582,8 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
       for (int a = 0; a < ND; ++a) { ctl[1 + a] = origin[a]; ctl[4 + a] = wshape[a]; }
     }
     wsync();
+    // the start vector need not satisfy the constraints: restore feasibility first
+    retr_fail = m > 0 && !retract(vt, cvt, Cjt, cpair + MAXC);
     fill_fpar(vt, size_is_var || round == 0);
     it = 0;
     return BP_EVAL_INIT;
@@ -780,19 +877,18 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           // the parked tiles overwrote columns of the row tiles: clear what rows never rewrite
           // (columns > nv are read by the MFMA but only feed entries nobody looks at)
         }
-        eval_constraints(vt, cvt, Cjt, cpair + MAXC);
+        if (ctl[7] != 0) St = NAN;   // a size of 0 (its lower bound): no valid model (oracle: model_nan)
       }
       bool accept = false;
       if (phase == BP_EVAL_INIT) {
         if (P == 0) { status = CTR_STATUS_OUT_OF_BOUNDS; failed = true; }
-        else if (!isfinite(St)) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
-        mu = 1e-3; nu = 2.; sigma = 0.; tau = 1.; last_acc = true; gain = INFINITY;
+        else if (!isfinite(St) || retr_fail) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+        mu = 1e-3; nu = 2.; last_acc = true; gain = INFINITY;
         Pround = P;
         accept = !failed;
       } else if (phase == BP_EVAL_TRIAL) {
-        double cnt = 0.;
-        for (int r = 0; r < m; ++r) cnt += fabs(cvt[r]);
-        double act = 0.5 * (S - St) + (m ? sigma * (cn - cnt) : 0.);
+        // every iterate is feasible (retraction): a step is judged by the objective alone
+        double act = 0.5 * (S - St);
         act = bcast0(act);
         if (isfinite(St) && pred > 0. && act > 0.) {
           const double rho = act / pred, t = 2. * rho - 1.;
@@ -800,14 +896,10 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           mu *= f > 1. / 3. ? f : 1. / 3.;
           nu = 2.;
           gain = act / (0.5 * S + 1e-300);
-          tau = tau < 0.5 ? 2. * tau : 1.;
           accept = true;
           last_acc = true;
         } else {
           mu *= nu; nu *= 2.; last_acc = false;
-          // the linearised constraints promised more than half of what the trial delivered:
-          // shorten the normal step as well
-          if (m && cnt > cn_pred + 0.5 * (cn - cn_pred)) tau *= 0.5;
           if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
         }
       }
@@ -862,15 +954,40 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
       STAMP(2);
       bool converged = false;
       if (!failed && it >= maxiter) {
-        // iteration limit: a stationary, feasible point still counts as converged (see solve() of the oracle)
-        double cnow = 0.;
-        for (int r = 0; r < m; ++r) cnow += fabs(cv[r]);
-        if (gain <= CTR_STALL_TOL && cnow <= 1e-10) converged = true;
+        // iteration limit: a stationary point still counts as converged (see solve() of the oracle)
+        if (gain <= CTR_STALL_TOL) converged = true;
         else { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
       }
       if (!failed && !converged) {
         ++it;
         ++iters;
+        // least-squares multipliers lam = -(C C^T)^-1 C g over the variables the box does not
+        // pin (oracle solve(): the ones that go with the minimum-norm retraction)
+        double mult0[MAXC];
+#pragma unroll
+        for (int r = 0; r < MAXC; ++r) mult0[r] = 0.;
+        if (m) {
+          double* ry = cv + 18;
+          if (lane < m * m) {
+            const int r = lane / m, s2 = lane % m;
+            double t = 0.;
+            for (int i = 0; i < nv; ++i)
+              if (lo[i] < hi[i]) t += Cj[r * LDC + i] * Cj[s2 * LDC + i];
+            Sc[r * MAXC + s2] = t;
+          }
+          if (lane < m) {
+            double t = 0.;
+            for (int i = 0; i < nv; ++i)
+              if (lo[i] < hi[i]) t -= Cj[lane * LDC + i] * Mp[tri(i + 1)];
+            ry[lane] = t;
+          }
+          wsync();
+          small_spd_solve(Sc, ry);
+          const bool okl = flag[0] != 0.;
+#pragma unroll
+          for (int r = 0; r < MAXC; ++r) mult0[r] = (okl && r < m) ? ry[r] : 0.;
+          wsync();
+        }
         // active set: fixed if at a bound and the Lagrangian gradient pushes outward
         int nf = 0;
         bool is_free = false;   // of variable `lane` (all that the register solve needs)
@@ -887,7 +1004,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             bool fre = false;
             if (i < nv) {
               double gl = Mp[tri(i + 1)];
-              for (int r = 0; r < m; ++r) gl += Cj[r * LDC + i] * mult[r];
+              for (int r = 0; r < m; ++r) gl += Cj[r * LDC + i] * mult0[r];
               const bool fixed = (lo[i] == hi[i]) || (v[i] <= lo[i] && gl > 0.) || (v[i] >= hi[i] && gl < 0.);
               fre = !fixed;
             }
@@ -904,16 +1021,12 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           converged = true;
         } else {
           // Model Hessian.  First choice: the exact one, J^T J + sum_p r_p d2r_p (signal and
-          // positions of every feature: qvar) + sum_r mult_r d2c_r (ccurv, multipliers of the
-          // last step).  Where that is not positive definite on the free variables, or its
-          // projected step is not a descent step of the model, J^T J is used for this
-          // iteration instead.  Same sequence as solve() of oracle/ctr_oracle.c.
-          double mult0[MAXC];
-#pragma unroll
-          for (int r = 0; r < MAXC; ++r) mult0[r] = r < m ? mult[r] : 0.;
-          cn = 0.;
-          for (int r = 0; r < m; ++r) cn += fabs(cv[r]);
-          double stepmax = 0., sigma_t = sigma;
+          // positions of every feature: qvar) + sum_r lam_r d2c_r (ccurv).  Where that is not
+          // positive definite on the free variables, or its projected step is not a descent
+          // step of the model, the second-order part of the residuals is dropped, then (for
+          // constrained fits) the curvature of the constraints as well: J^T J.  Same sequence
+          // as solve() of oracle/ctr_oracle.c.
+          double stepmax = 0.;
           // second-order part between two variables (0 unless both belong to one feature)
           auto qvar = [&](int gi, int gj) -> double {
             const int ia = vinfo[gi], ib = vinfo[gj];
@@ -963,8 +1076,9 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           }
           STAMP(8);
 #pragma nounroll
-          for (int attempt = newton_on ? 1 : 0; attempt >= 0 && !ok_step; --attempt) {
-            const bool nwt = attempt == 1;
+          for (int attempt = (newton_on ? 1 : 0) + (m ? 1 : 0); attempt >= 0 && !ok_step; --attempt) {
+            const bool nwt = newton_on && attempt == (m ? 2 : 1);   // with the second-order part Q
+            const bool use_cc = m != 0 && attempt >= 1;             // with the constraints' curvature
             bool ok_a = true;
             bool have_dl = false;
             if (reg_solve) {
@@ -995,7 +1109,8 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
                 const int b = e - tri(a);
                 double h = Msym(Mp, fr[a] + 1, fr[b] + 1);
                 const double hs = a == b ? mu * (h > 1e-300 ? h : 1.) : 0.;
-                if (nwt) { h += qvar(fr[a], fr[b]); h += ccurv(fr[a], fr[b]); }
+                if (nwt) h += qvar(fr[a], fr[b]);
+                if (use_cc) h += ccurv(fr[a], fr[b]);
                 Hp[e] = h + hs;
               }
               wsync();
@@ -1009,8 +1124,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
                 chol_solve_w(Hp, dl, nf, w, 1, 0, lane);
                 if (m) {
                   chol_solve_w(Hp, dl, nf, Y, m, LDC, lane);
-                  // (C H^-1 C^T) mult = tau c - C H^-1 g   (range-space form of the KKT step,
-                  // normal step damped: C d = -tau c)
+                  // tangent step, range-space form: (C H^-1 C^T) mult = -C H^-1 g, so that C d = 0
                   if (lane < m * m) {
                     const int r = lane / m, s2 = lane % m;
                     double t = 0.;
@@ -1018,44 +1132,13 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
                     Sc[r * MAXC + s2] = t;
                   }
                   if (lane < m) {
-                    double t = tau * cv[lane];
+                    double t = 0.;
                     for (int a = 0; a < nf; ++a) t -= Cj[lane * LDC + fr[a]] * w[a];
                     mult[lane] = t;
                   }
                   wsync();
-                  if (lane == 0) {
-                    double tr = 0.;
-                    for (int r = 0; r < m; ++r) tr += Sc[r * MAXC + r];
-                    for (int r = 0; r < m; ++r) Sc[r * MAXC + r] += 1e-14 * tr + 1e-300;
-                    bool okc = true;
-                    for (int j = 0; j < m && okc; ++j) {
-                      double d = Sc[j * MAXC + j];
-                      for (int q = 0; q < j; ++q) d -= Sc[j * MAXC + q] * Sc[j * MAXC + q];
-                      if (!(d > 0.) || !isfinite(d)) { okc = false; break; }
-                      d = sqrt(d);
-                      Sc[j * MAXC + j] = d;
-                      for (int i = j + 1; i < m; ++i) {
-                        double s2 = Sc[i * MAXC + j];
-                        for (int q = 0; q < j; ++q) s2 -= Sc[i * MAXC + q] * Sc[j * MAXC + q];
-                        Sc[i * MAXC + j] = s2 / d;
-                      }
-                    }
-                    if (okc) {
-                      for (int i = 0; i < m; ++i) {
-                        double s2 = mult[i];
-                        for (int q = 0; q < i; ++q) s2 -= Sc[i * MAXC + q] * mult[q];
-                        mult[i] = s2 / Sc[i * MAXC + i];
-                      }
-                      for (int i = m - 1; i >= 0; --i) {
-                        double s2 = mult[i];
-                        for (int q = i + 1; q < m; ++q) s2 -= Sc[q * MAXC + i] * mult[q];
-                        mult[i] = s2 / Sc[i * MAXC + i];
-                      }
-                    } else {
-                      for (int i = 0; i < m; ++i) mult[i] = 0.;
-                    }
-                    flag[0] = okc ? 1. : 0.;
-                  }
+                  small_spd_solve(Sc, mult);
+                  if (flag[0] == 0. && lane < m) mult[lane] = 0.;
                   wsync();
                   ok_a = flag[0] != 0.;
                 }
@@ -1073,13 +1156,16 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
               }
               wsync();
             }
-            // projected trial point
+            // projected trial point, retracted onto the constraint manifold
+            for (int i = lane; i < nv; i += WAVE) {
+              const double t = v[i] + dl[i];
+              vt[i] = t < lo[i] ? lo[i] : (t > hi[i] ? hi[i] : t);
+            }
+            wsync();
+            if (m && !retract(vt, cvt, Cjt, cpair + MAXC)) continue;
             stepmax = 0.;
             for (int i = lane; i < nv; i += WAVE) {
-              double t = v[i] + dl[i];
-              t = t < lo[i] ? lo[i] : (t > hi[i] ? hi[i] : t);
-              vt[i] = t;
-              const double d = t - v[i];
+              const double d = vt[i] - v[i];
               dl[i] = d;
               stepmax = fmax(stepmax, fabs(d) / (fabs(v[i]) + 1.));
             }
@@ -1099,46 +1185,29 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
                 }
               } else if (nwt && vinfo[i] >= 0) {
                 const int j0 = L.nshared + (vinfo[i] >> 3) * L.npf;
+                // (with constraints the model of the OBJECTIVE along the retracted step: the
+                // curvature of the manifold is in dl itself, not in the matrix)
                 for (int j = j0; j < j0 + L.npf; ++j) t += qvar(i, j) * dl[j];
-                if (m)
-                  for (int j = L.nshared; j < nv; ++j) t += ccurv(i, j) * dl[j];
               }
               partial += dl[i] * (Mp[tri(i + 1)] + 0.5 * t);
             }
             pred = -wave_sum(partial);
-            if (m) {
-              double cn_lin = 0., mmax = 0.;
-              for (int r = 0; r < m; ++r) {
-                double t = cv[r];
-                for (int i = 0; i < nv; ++i) t += Cj[r * LDC + i] * dl[i];
-                cn_lin += fabs(t);
-                mmax = fmax(mmax, fabs(mult[r]));
-              }
-              // penalty weight of the l1 merit function, Powell's rule (as SLSQP's line search)
-              sigma_t = 0.5 * (sigma + mmax);
-              if (sigma_t < mmax) sigma_t = mmax;
-              pred += sigma_t * (cn - cn_lin);
-              cn_pred = cn_lin;
-            }
             pred = bcast0(pred);
             stepmax = bcast0(stepmax);
             STAMP(11);
-            if (nwt && !(pred > -tiny)) continue;
+            if (attempt >= 1 && !(pred > -tiny)) continue;
             ok_step = true;
           }
-          sigma = sigma_t;   // uniform: computed from LDS data by every lane alike
           STAMP(4);
           if (!ok_step) {
             mu *= nu; nu *= 2.; last_acc = false;
             if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
             next = BP_STEP_ONLY;
           } else {
-            const bool feasible = (m == 0) || (cn <= 1e-10);
-            converged = feasible && ((last_acc && stepmax <= xtol) || fabs(pred) <= tiny);
+            converged = (last_acc && stepmax <= xtol) || fabs(pred) <= tiny;
             next = BP_EVAL_TRIAL;
-            if (!converged && m == 0 && !(pred > 0.)) {
-              // the model itself predicts no decrease: rejected without a pixel pass (with
-              // constraints the trial's violation still steers tau, so those are evaluated)
+            if (!converged && !(pred > 0.)) {
+              // the model itself predicts no decrease: rejected without a pixel pass
               mu *= nu; nu *= 2.; last_acc = false;
               if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
               next = BP_STEP_ONLY;

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
   double v[NV], vt[NV];
   double mco[NF][ND], isz2[NF][ND];  // mask centres, 1/size^2 (p0 rows are re-read from HBM when needed)
   double mu = 1e-3, nu = 2., S = 0., pred = 0., norm = 1., rms = NAN;
-  bool last_acc = true;
+  bool last_acc = true, bad_size = false;
   double gain = INFINITY;  // relative decrease of S by the last accepted step
   const char* frame = nullptr;
 
@@ -103,6 +103,7 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
         const double* low = k.low + (size_t)f0 * NP;
         const double* high = k.high + (size_t)f0 * NP;
         bool finite = true;
+        bad_size = false;
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
 #pragma unroll
@@ -113,6 +114,7 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
             mco[i][a] = params[i * NP + 2 + a];
             const double sz = params[i * NP + (ISO ? 2 + ND : 2 + ND + a)];
             isz2[i][a] = 1. / (sz * sz);
+            bad_size = bad_size || !(sz > 0.);   // no valid model (oracle eval_cluster: model_nan)
           }
         }
         // start vector: mean background (refine.py:361), loosest background bound (fitfunc.py:554-557)
@@ -302,7 +304,7 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
       bool failed = false;
       if (phase == PH_EVAL_INIT) {
         if (P == 0) { status = CTR_STATUS_OUT_OF_BOUNDS; failed = true; }
-        else if (!isfinite(St)) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+        else if (!isfinite(St) || bad_size) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
         mu = 1e-3; nu = 2.; last_acc = true; gain = INFINITY;
         Pround = P;
       }

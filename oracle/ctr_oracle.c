@@ -247,6 +247,7 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
   int nz[MAXV];
   double S = 0.;
   long P = 0;
+  int model_nan = 0;
   const int bgvar = L->var_of[0];
   const double bg = par(c, v, 0, 0);
   const int w0 = nd == 3 ? c->wshape[0] : 1, w1 = c->wshape[nd - 2], w2 = c->wshape[nd - 1];
@@ -264,7 +265,7 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
         double mesh[3];
         size_t off;
         int any = 0, nnz = 0, nhf = 0;
-        double res = 0.;
+        double res = 0., pv = 0.;
         if (nd == 3) {
           idx[0] = z; idx[1] = y; idx[2] = x;
           off = ((size_t)(z + c->origin[0]) * fshape[1] + (y + c->origin[1])) * fshape[2] + (x + c->origin[2]);
@@ -277,7 +278,8 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
           if (!in_mask(nd, idx, c->mcoords + i * nd, c->origin, c->p->radius)) continue;
           if (!any) {
             any = 1;
-            res = pixel(c->frame, dtype, off) - bg;
+            pv = pixel(c->frame, dtype, off);
+            res = pv - bg;
             if (bgvar >= 0) { row[bgvar] = -1.; nz[nnz++] = bgvar; }
           }
           for (int k = 1; k < np; ++k) prm[k] = par(c, v, i, k);
@@ -286,6 +288,7 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
           if (c->p->isotropic) {
             const double size = prm[2 + nd];
             double q = 0.;
+            if (!(size > 0.)) model_nan = 1; /* a size of 0 (its lower bound): no valid model */
             for (int a = nd - 1; a >= 0; --a) { /* x first (fitfunc.py:17,40) */
               double d = mesh[a] - prm[2 + a];
               q += d * d;
@@ -296,6 +299,7 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
           } else {
             for (int a = nd - 1; a >= 0; --a) {
               double d = mesh[a] - prm[2 + a], sz = prm[2 + nd + a];
+              if (!(sz > 0.)) model_nan = 1;
               r2 += d * d / (sz * sz);
               dr2[a] = (prm[2 + a] - mesh[a]) * (2. / (sz * sz));
               dr2[nd + a] = d * d * (-2. / (sz * sz * sz));
@@ -330,7 +334,10 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
         }
         if (!any) continue;
         ++P;
-        if (res != res) continue; /* nansum (fitfunc.py:449,483) */
+        if (res != res) { /* nansum (fitfunc.py:449,483): a NaN pixel of the IMAGE is skipped */
+          if (pv == pv) model_nan = 1; /* a NaN of the MODEL (a size of 0): no valid evaluation */
+          continue;
+        }
         S += res * res;
         if (g) {
           for (int s = 0; s < nnz; ++s) {
@@ -367,7 +374,7 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
       }
     }
   }
-  *S_out = S;
+  *S_out = model_nan ? NAN : S;
   *P_out = P;
 }
 
@@ -409,15 +416,76 @@ static void chol_solve(const double* Lm, int n, int ld, double* x) {
 /* diagnostic switch: 0 = Gauss-Newton model only (for A/B measurements of the oracle itself) */
 static int use_newton = 1;
 void ctro_set_newton(int on) { use_newton = on; }
+/* diagnostic switch: print one line per solver iteration to stderr */
+static int trace = 0;
+void ctro_set_trace(int on) { trace = on; }
 
 typedef struct { double S; long P; int iters; int ok; } solve_t;
 
-static double l1norm(const double* c, int m) {
-  double s = 0.;
-  for (int i = 0; i < m; ++i) s += fabs(c[i]);
-  return s;
+/* Retraction onto the constraint manifold c(x) = 0 (constraints.py:59-137): minimum-norm
+ * Newton steps x <- x - C^T (C C^T)^-1 c over the position variables that the box leaves
+ * free, clipped to the box.  The constraints are quadratics of the positions, so a point
+ * near the manifold needs 3-5 steps.  On success cv / Cj / pair_of describe the constraints
+ * at the returned point.  0: no convergence (degenerate geometry, or the box is in the way). */
+#define RETRACT_MAXIT 30
+#define RETRACT_TOL 1e-13
+static int retract(const ctx_t* c, double* x, const double* lo, const double* hi,
+                   double* cv, double* Cj, int* pair_of) {
+  const int nv = c->L.nv, m = c->n_cons;
+  double G[MAXC * MAXC], y[MAXC];
+  int pinned[MAXV];
+  for (int iter = 0; iter <= RETRACT_MAXIT; ++iter) {
+    double cmax = 0.;
+    eval_constraints(c, x, cv, Cj, pair_of);
+    for (int r = 0; r < m; ++r) if (fabs(cv[r]) > cmax) cmax = fabs(cv[r]);
+    if (!(cmax == cmax)) return 0;
+    if (cmax <= RETRACT_TOL) return 1;
+    if (iter == RETRACT_MAXIT) break;
+    /* pass 0: all variables the box does not fix; a variable ON a bound that this correction
+     * would push outward is pinned and the correction recomputed without it (pass 1) */
+    for (int i = 0; i < nv; ++i) pinned[i] = !(lo[i] < hi[i]);
+    for (int pass = 0; pass < 2; ++pass) {
+      double tr = 0.;
+      int changed = 0;
+      for (int r = 0; r < m; ++r)
+        for (int s = 0; s <= r; ++s) {
+          double t = 0.;
+          for (int i = 0; i < nv; ++i)
+            if (!pinned[i]) t += Cj[r * nv + i] * Cj[s * nv + i];
+          G[r * m + s] = t;
+          if (r == s) tr += t;
+        }
+      if (!(tr > 0.)) return 0;
+      for (int r = 0; r < m; ++r) { G[r * m + r] += 1e-14 * tr + 1e-300; y[r] = cv[r]; }
+      if (!cholesky(G, m, m)) return 0;
+      chol_solve(G, m, m, y);
+      if (pass == 1) break;
+      for (int i = 0; i < nv; ++i) {
+        if (pinned[i]) continue;
+        double t = 0.;
+        for (int r = 0; r < m; ++r) t += Cj[r * nv + i] * y[r];
+        if ((x[i] <= lo[i] && t > 0.) || (x[i] >= hi[i] && t < 0.)) { pinned[i] = 1; changed = 1; }
+      }
+      if (!changed) break;
+    }
+    for (int i = 0; i < nv; ++i) {
+      if (pinned[i]) continue;
+      double t = 0.;
+      for (int r = 0; r < m; ++r) t += Cj[r * nv + i] * y[r];
+      if (t == 0.) continue;
+      t = x[i] - t;
+      x[i] = t < lo[i] ? lo[i] : (t > hi[i] ? hi[i] : t);
+    }
+  }
+  return 0;
 }
 
+/* One solver run (one re-window round).  Unconstrained clusters: bounded Levenberg-Marquardt
+ * with an active set for the box.  Constrained clusters (dimer / trimer / tetramer): the same
+ * iteration as a FEASIBLE-POINT method -- every iterate lies on the constraint manifold: the
+ * step is the minimiser of the damped model in the tangent space (C d = 0, range-space form),
+ * the trial point is retracted onto the manifold, and a step is judged by the objective alone.
+ * No merit function and no penalty weight, hence no Maratos effect. */
 static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const double* hi,
                      double* v /* out */) {
   const int nv = c->L.nv, m = c->n_cons;
@@ -439,30 +507,58 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
   double *Y = malloc(sizeof(double) * nv * MAXC), *Cj = malloc(sizeof(double) * nv * MAXC);
   double *Cjt = malloc(sizeof(double) * nv * MAXC);
   int* fr = malloc(sizeof(int) * nv);
-  double cv[MAXC], cvt[MAXC], mult[MAXC], Sc[MAXC * MAXC];
-  double S, St, mu, nu = 2., sigma = 0., tau = 1.;
+  double cv[MAXC], cvt[MAXC], mult[MAXC], lam[MAXC], Sc[MAXC * MAXC];
+  double S, St, mu, nu = 2.;
   long P;
-  int last_accepted = 1, it;
-  double gain = INFINITY; /* relative merit decrease of the last accepted step */
+  int last_accepted = 1, it = 0;
+  double gain = INFINITY; /* relative decrease of the objective by the last accepted step */
 
   for (int i = 0; i < nv; ++i) {
     if (lo[i] > hi[i]) goto done; /* infeasible box (SciPy raises ValueError) */
     v[i] = v0[i] < lo[i] ? lo[i] : (v0[i] > hi[i] ? hi[i] : v0[i]);
   }
+  memset(mult, 0, sizeof mult);
+  memset(lam, 0, sizeof lam);
+  memset(cv, 0, sizeof cv);
+  /* the start vector need not satisfy the constraints: restore feasibility first */
+  if (m && !retract(c, v, lo, hi, cv, Cj, pair_of)) {
+    eval_cluster(c, v, &S, NULL, NULL, NULL, &P);
+    out.P = P;
+    goto done;
+  }
   eval_cluster(c, v, &S, g, A, newton ? Q : NULL, &P);
   out.P = P;
   if (P == 0 || !isfinite(S)) goto done;
-  eval_constraints(c, v, cv, Cj, pair_of);
-  memset(mult, 0, sizeof mult);
   mu = 1e-3; /* multiplies the Marquardt diagonal below */
 
   for (it = 0; it < maxiter; ++it) {
     int nf = 0;
     out.iters = it + 1;
+    /* least-squares multipliers lam = -(C C^T)^-1 C g over the variables the box does not pin:
+     * the ones that go with the minimum-norm retraction (g . n = lam^T C n for its normal
+     * correction n), hence the ones whose curvature term makes the tangent-space model agree
+     * with the objective along the retracted step to second order */
+    if (m) {
+      double tr = 0.;
+      for (int r = 0; r < m; ++r) {
+        for (int s = 0; s <= r; ++s) {
+          double t = 0.;
+          for (int i = 0; i < nv; ++i) if (lo[i] < hi[i]) t += Cj[r * nv + i] * Cj[s * nv + i];
+          Sc[r * m + s] = t;
+        }
+        double t = 0.;
+        for (int i = 0; i < nv; ++i) if (lo[i] < hi[i]) t -= Cj[r * nv + i] * g[i];
+        lam[r] = t;
+        tr += Sc[r * m + r];
+      }
+      for (int r = 0; r < m; ++r) Sc[r * m + r] += 1e-14 * tr + 1e-300;
+      if (tr > 0. && cholesky(Sc, m, m)) chol_solve(Sc, m, m, lam);
+      else memset(lam, 0, sizeof lam);
+    }
     /* active set: fixed if at a bound and the Lagrangian gradient pushes outward */
     for (int i = 0; i < nv; ++i) {
       double gl = g[i];
-      for (int r = 0; r < m; ++r) gl += Cj[r * nv + i] * mult[r];
+      for (int r = 0; r < m; ++r) gl += Cj[r * nv + i] * lam[r];
       int fixed = (lo[i] == hi[i]) || (v[i] <= lo[i] && gl > 0.) || (v[i] >= hi[i] && gl < 0.);
       if (!fixed) fr[nf++] = i;
     }
@@ -472,21 +568,23 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
      * constrained fits).  Where that is not positive definite on the free variables, or its
      * projected step is not a descent step of the model, the Gauss-Newton matrix J^T J is
      * used for this iteration instead. */
-    double stepmax = 0., pred = 0., cn = l1norm(cv, m), sigma_t = sigma, cn_pred = 0.;
-    double mult0[MAXC];
+    double stepmax = 0., pred = 0.;
     int step_ok = 0;
-    memcpy(mult0, mult, sizeof mult0);
-    for (int attempt = newton ? 1 : 0; attempt >= 0 && !step_ok; --attempt) {
+    /* models tried in turn: with the second-order part Q of the residuals (and the curvature
+     * of the constraints), without Q, and -- constrained fits -- plain J^T J */
+    for (int attempt = (newton ? 1 : 0) + (m ? 1 : 0); attempt >= 0 && !step_ok; --attempt) {
+      const int use_q = newton && attempt == (m ? 2 : 1), use_cc = m && attempt >= 1;
       memcpy(B, A, sizeof(double) * nv * nv);
-      if (attempt == 1) {
+      if (use_q)
         for (int i = 0; i < nv * nv; ++i) B[i] += Q[i];
-        /* curvature of the constraints (c_r = 1 - |dp/dist|^2), multipliers of the last step */
+      if (use_cc) {
+        /* curvature of the constraints (c_r = 1 - |dp/dist|^2) */
         for (int r = 0; r < m; ++r) {
           int i0 = PAIRS[pair_of[r]][0], i1 = PAIRS[pair_of[r]][1];
           for (int a = 0; a < c->L.nd; ++a) {
             int k = 2 + a, b = c->L.var_of[k];
             if (b < 0 || !c->L.per_feat[k]) continue;
-            double da = c->p->constraint_dist[a], t = -2. * mult0[r] / (da * da);
+            double da = c->p->constraint_dist[a], t = -2. * lam[r] / (da * da);
             B[(b + i0) * nv + b + i0] += t;
             B[(b + i1) * nv + b + i1] += t;
             B[(b + i0) * nv + b + i1] -= t;
@@ -499,14 +597,15 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
         double d = A[fr[a] * nv + fr[a]];
         H[a * nf + a] += mu * (d > 1e-300 ? d : 1.);
       }
-      if (!cholesky(H, nf, nf)) continue;
+      if (!cholesky(H, nf, nf)) { if (trace > 2) fprintf(stderr, "   it %d attempt %d: H not PD (mu %g)\n", it, attempt, mu); continue; }
       for (int a = 0; a < nf; ++a) w[a] = g[fr[a]];
       chol_solve(H, nf, nf, w); /* w = H^-1 g_F */
       memset(dl, 0, sizeof(double) * nv);
       if (m == 0) {
         for (int a = 0; a < nf; ++a) dl[fr[a]] = -w[a];
       } else {
-        /* range-space step: (C H^-1 C^T) mult = c - C H^-1 g ; d = -H^-1 (g + C^T mult) */
+        /* tangent step, range-space form: (C H^-1 C^T) mult = -C H^-1 g ;
+         * d = -H^-1 (g + C^T mult), so that C d = 0 */
         for (int r = 0; r < m; ++r) {
           for (int a = 0; a < nf; ++a) Y[r * nf + a] = Cj[r * nv + fr[a]];
           chol_solve(H, nf, nf, Y + r * nf);
@@ -517,7 +616,7 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
             for (int a = 0; a < nf; ++a) t += Cj[r * nv + fr[a]] * Y[s * nf + a];
             Sc[r * m + s] = t;
           }
-          double t = tau * cv[r]; /* damped normal step: C d = -tau c */
+          double t = 0.;
           for (int a = 0; a < nf; ++a) t -= Cj[r * nv + fr[a]] * w[a];
           mult[r] = t;
         }
@@ -525,6 +624,7 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
           double tr = 0.;
           for (int r = 0; r < m; ++r) tr += Sc[r * m + r];
           for (int r = 0; r < m; ++r) Sc[r * m + r] += 1e-14 * tr + 1e-300;
+          if (!(tr > 0.)) { memset(mult, 0, sizeof mult); continue; }
         }
         if (!cholesky(Sc, m, m)) { memset(mult, 0, sizeof mult); continue; }
         chol_solve(Sc, m, m, mult);
@@ -534,53 +634,43 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
           dl[fr[a]] = -t;
         }
       }
-      /* projected trial point */
+      /* projected trial point, retracted onto the constraint manifold */
+      for (int i = 0; i < nv; ++i) {
+        double t = v[i] + dl[i];
+        vt[i] = t < lo[i] ? lo[i] : (t > hi[i] ? hi[i] : t);
+      }
+      if (m && !retract(c, vt, lo, hi, cvt, Cjt, pair_of_t)) { if (trace > 2) fprintf(stderr, "   it %d attempt %d: retraction failed\n", it, attempt); continue; }
       double gd = 0., dAd = 0.;
       stepmax = 0.;
       for (int i = 0; i < nv; ++i) {
-        double t = v[i] + dl[i];
-        t = t < lo[i] ? lo[i] : (t > hi[i] ? hi[i] : t);
-        vt[i] = t;
-        dl[i] = t - v[i];
+        dl[i] = vt[i] - v[i];
         double rel = fabs(dl[i]) / (fabs(v[i]) + 1.);
         if (rel > stepmax) stepmax = rel;
       }
+      /* predicted decrease of the OBJECTIVE along the actual (retracted) step; with
+       * constraints its model is A (+ Q): the curvature of the manifold is in dl itself */
       for (int i = 0; i < nv; ++i) {
         double t = 0.;
-        for (int j = 0; j < nv; ++j) t += B[i * nv + j] * dl[j];
+        for (int j = 0; j < nv; ++j)
+          t += (m ? A[i * nv + j] + (use_q ? Q[i * nv + j] : 0.) : B[i * nv + j]) * dl[j];
         dAd += dl[i] * t;
         gd += g[i] * dl[i];
       }
       pred = -(gd + 0.5 * dAd);
-      if (m) {
-        double mmax = 0., cn_lin = 0.;
-        for (int r = 0; r < m; ++r) {
-          double t = cv[r];
-          for (int i = 0; i < nv; ++i) t += Cj[r * nv + i] * dl[i];
-          cn_lin += fabs(t);
-          if (fabs(mult[r]) > mmax) mmax = fabs(mult[r]);
-        }
-        /* penalty weight of the l1 merit function, Powell's rule (as SLSQP's line search) */
-        sigma_t = 0.5 * (sigma + mmax);
-        if (sigma_t < mmax) sigma_t = mmax;
-        pred += sigma_t * (cn - cn_lin);
-        cn_pred = cn_lin;
-      }
-      if (attempt == 1 && !(pred > -(ftol * (0.5 * S) + 1e-300))) continue;
+      if (attempt >= 1 && !(pred > -(ftol * (0.5 * S) + 1e-300))) { if (trace > 2) fprintf(stderr, "   it %d attempt %d: pred %g\n", it, attempt, pred); continue; }
       step_ok = 1;
     }
-    sigma = sigma_t;
     if (!step_ok) { mu *= nu; nu *= 2.; last_accepted = 0; if (mu > 1e30) break; continue; }
     /* converged: negligible step after an accepted one, or negligible model change.
      * A clearly NEGATIVE predicted decrease (the projection onto the box turned the
      * step uphill) is not convergence: the trial below is then rejected and mu grows,
      * which turns the step towards the projected gradient. */
-    int feasible = (m == 0) || (cn <= 1e-10);
-    if (feasible && ((last_accepted && stepmax <= xtol) || fabs(pred) <= ftol * (0.5 * S) + 1e-300)) {
+    if ((last_accepted && stepmax <= xtol) || fabs(pred) <= ftol * (0.5 * S) + 1e-300) {
       out.ok = 1;
       break;
     }
-    if (m == 0 && !(pred > 0.)) {
+    if (trace > 2 && !(pred > 0.)) fprintf(stderr, "   it %d: pred %g, no trial\n", it, pred);
+    if (!(pred > 0.)) {
       /* the model itself predicts no decrease (projection): rejected without looking at the
        * pixels -- the test below would reject it whatever the trial gave */
       mu *= nu;
@@ -590,16 +680,23 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
       continue;
     }
     eval_cluster(c, vt, &St, gt, At, newton ? Qt : NULL, &P);
-    eval_constraints(c, vt, cvt, Cjt, pair_of_t);
-    const double cnt = l1norm(cvt, m);
-    double act = 0.5 * (S - St) + (m ? sigma * (cn - cnt) : 0.);
+    double act = 0.5 * (S - St);
+    if (trace)
+      fprintf(stderr, "it %3d nf %d S %.10g St %.10g mu %.2e pred %.3e act %.3e step %.2e mult0 %.3e\n",
+              it, nf, S, St, mu, pred, act, stepmax, m ? mult[0] : 0.);
+    if (trace > 1) {
+      fprintf(stderr, "      vt:");
+      for (int i = 0; i < nv; ++i) fprintf(stderr, " %.6g", vt[i]);
+      fprintf(stderr, "\n      g :");
+      for (int i = 0; i < nv; ++i) fprintf(stderr, " %.3g", g[i]);
+      fprintf(stderr, "\n");
+    }
     if (isfinite(St) && pred > 0. && act > 0.) {
       double rho = act / pred, t = 2. * rho - 1.;
       double f = 1. - t * t * t;
       mu *= f > 1. / 3. ? f : 1. / 3.;
       nu = 2.;
       gain = act / (0.5 * S + 1e-300);
-      tau = tau < 0.5 ? 2. * tau : 1.;
       memcpy(v, vt, sizeof(double) * nv);
       memcpy(g, gt, sizeof(double) * nv);
       memcpy(A, At, sizeof(double) * nv * nv);
@@ -612,9 +709,6 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
     } else {
       mu *= nu;
       nu *= 2.;
-      /* the linearised constraints promised more than half of what the trial delivered:
-       * shorten the normal step as well */
-      if (m && cnt > cn_pred + 0.5 * (cn - cn_pred)) tau *= 0.5;
       last_accepted = 0;
       if (mu > 1e30) break;
     }
@@ -622,7 +716,7 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
   /* iteration limit with a stationary objective: the last accepted step lowered it by
    * less than STALL_TOL (relative).  The reference's SLSQP stops at |dF| < 1e-6 absolute
    * (refine.py:243,373-375), far looser, so it reports such fits as converged. */
-  if (!out.ok && it == maxiter && gain <= STALL_TOL && (m == 0 || l1norm(cv, m) <= 1e-10)) out.ok = 1;
+  if (!out.ok && it == maxiter && gain <= STALL_TOL) out.ok = 1;
   out.S = S;
 done:
   free(g); free(A); free(gt); free(At); free(H); free(vt); free(dl); free(w);

@@ -51,6 +51,9 @@ def test_golden_case_engine_vs_oracle_and_reference(engine, oracle, name):
         return
     A, B = case.ref('A'), case.ref('B')
     pc = case.pos_columns
+    if _cases.is_solver_specific(name):
+        assert _cases.check_solver_specific(name, res, A, B, pc) >= 2
+        return
     assert_equal(np.isnan(res['cost'].values), np.isnan(B['cost'].values))
     ok = ~np.isnan(res['cost'].values)
     better = ok & (res['cost'].values < B['cost'].values - 1e-7)

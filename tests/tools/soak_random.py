@@ -19,6 +19,8 @@ n_clusters = 0
 worst = 0.
 for seed in range(first, first + n_seeds):
     f0, im, diameter, kw = _cases.random_case(seed)
+    if os.environ.get('SOAK_CONSTRAINED_ONLY') and 'constraints' not in kw:
+        continue
     prep = cta.prepare_batch(f0, im, diameter, **kw)
     if os.environ.get('SOAK_THROUGHPUT'):
         prep.problem.flags |= _abi.FLAG_THROUGHPUT   # scheduling flag: same results expected
