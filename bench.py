@@ -74,6 +74,29 @@ def cpu_baseline(problem, host_batch):
     return out
 
 
+def algorithmic_flops(problem, hb, n_iter):
+    """algorithmic flops of the solver iterations of one pass over the batch,
+    with the MEASURED iteration counts.  Per iteration of a cluster of n features (d = ndim,
+    p = mask pixels of a feature, P = union pixels, taken as n p: overlaps make it smaller):
+      flops_it = sum_i p (6 d + 8) + P nv (nv + 1) + 2 P nv + 2 P + nv^3 / 3,  exps_it = sum_i p.
+    Returns (flops, exps, {cluster size: (clusters, mean iterations)})."""
+    d = int(problem.ndim)
+    r = [int(problem.radius[a]) for a in range(d)]
+    grids = np.meshgrid(*[np.arange(-x, x + 1) / float(x) for x in r], indexing='ij')
+    p = int((sum(g ** 2 for g in grids) <= 1.).sum())       # refine.py:43-44, centred mask
+    n = np.diff(hb.feat_offset).astype(np.int64)
+    modes = [int(problem.modes[k]) for k in range(int(problem.n_params))]
+    nv = sum((n if m == 1 else (1 if m != 0 else 0)) for m in modes)
+    P = n * p
+    flops_it = n * p * (6 * d + 8) + P * nv * (nv + 1) + 2 * P * nv + 2 * P + nv ** 3 / 3.
+    it = n_iter.astype(np.float64)
+    by_size = {}
+    for size in np.unique(n):
+        sel = n == size
+        by_size[int(size)] = (int(sel.sum()), float(it[sel].mean()))
+    return float((flops_it * it).sum()), float((n * p * it).sum()), by_size
+
+
 def main():
     args = parse()
     # Every size class of a batch is one kernel on its own stream (5 streams per engine
@@ -264,11 +287,22 @@ def main():
         rf = rf_alone if nfl == 1 else elapsed / args.steps
         peak = 8000.0
         traffic = None
+        traffic_source = None
         tf = os.path.join(ROOT, 'profiles', 'traffic_cfg2.json')
         if args.workload == 'cfg2' and args.frames == 256 and os.path.exists(tf):
-            # HBM bytes of the refine kernels from the committed rocprofv3 PMC passes
-            # (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction); see the file
-            traffic = json.load(open(tf))['refine_kernels']['bytes_corrected']
+            # HBM bytes of the refine kernels from the COMMITTED rocprofv3 PMC passes
+            # (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction) -- counters cannot be
+            # read from inside this process, so this is a profile of the same command, not of
+            # this run; see the file for the build it was taken on
+            tj = json.load(open(tf))
+            traffic = tj['refine_kernels']['bytes_corrected']
+            traffic_source = "committed profile (%s), not this run" % tj.get('profile', 'profiles/traffic_cfg2.json')
+        flops, exps, by_size = algorithmic_flops(prep.problem, hb, hb.n_iter)
+        fp64_peak = 78.6     # TFLOP/s, FP64 vector (MI355X_MICROARCH.md / SURVEY.md 8d)
+        valu = None
+        vf = os.path.join(ROOT, 'profiles', 'valu_cfg2.json')
+        if args.workload == 'cfg2' and args.frames == 256 and os.path.exists(vf):
+            valu = json.load(open(vf))
         result = {
             "metric": "cluster-fits/sec", "value": value, "unit": "cluster-fits/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -283,12 +317,23 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "refine stage: refine_small_kernel<2,1|2> + refine_block_kernel<2,iso,NT,W> (concurrent streams)",
                          "achieved": alg_bytes / rf / 1e9, "peak": peak, "unit": "GB/s",
                          "frac": alg_bytes / rf / 1e9 / peak, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": rf * 1e3,
                          "kernel_ms_one_batch_alone": rf_alone * 1e3},
             "roofline_frame_max": {"bound": "hbm", "kernel": "frame_max_kernel",
                                    "achieved": hb.frames.nbytes / fm / 1e9, "peak": peak,
                                    "unit": "GB/s", "frac": hb.frames.nbytes / fm / 1e9 / peak,
                                    "kernel_ms": fm * 1e3},
+            # the bound that matters for this path: the LM iterations run on chip,
+            # FP64 vector / transcendental bound; algorithmic flops with the measured iterations
+            "roofline_fp64_valu": {"bound": "valu-fp64", "achieved": flops / rf / 1e12, "peak": fp64_peak,
+                                   "unit": "TFLOP/s", "frac": flops / rf / 1e12 / fp64_peak,
+                                   "algorithmic_flops_per_launch": flops, "exp_per_launch": exps,
+                                   "iterations_by_cluster_size": {str(k): {"clusters": v[0], "mean_iterations": v[1]}
+                                                                  for k, v in sorted(by_size.items())},
+                                   "valu_busy": valu,
+                                   "note": "flops_it = sum p(6d+8) + P nv(nv+1) + 2 P nv + 2P + nv^3/3 per solver "
+                                           "iteration (SURVEY.md 8d), P = n p; x the measured n_iter of every cluster"},
             "host_prepare_s": t_host_prep,
             "gather_checked": gather_ok,
             "batches_in_flight": nfl,
@@ -313,15 +358,29 @@ def main():
             n_per = np.diff(hb.feat_offset)[sample]
             d_all = np.abs(gpu_out[rows][:, pos] - hb.params_out[rows][:, pos]).max(1)
             d = (gpu_out[rows][:, pos] - hb.params_out[rows][:, pos])[np.repeat(same_min, n_per)]
+            d_unf = (gpu_out[rows][:, pos] - hb.params_out[rows][:, pos])[np.repeat(ok_c, n_per)]
+            others = []
+            for c_i in np.flatnonzero(ok_c & ~same_min):
+                cl = int(sample[c_i])
+                sl = slice(hb.feat_offset[cl], hb.feat_offset[cl + 1])
+                others.append({"cluster": cl, "features": int(n_per[c_i]),
+                               "cost_engine": float(gpu_cost[cl]), "cost_slsqp": float(hb.cost[cl]),
+                               "lower_cost": "engine" if gpu_cost[cl] < hb.cost[cl] else "slsqp",
+                               "max_dpos_px": float(np.abs(gpu_out[sl][:, pos] - hb.params_out[sl][:, pos]).max())})
             result["parity_vs_scipy_slsqp_px"] = {
                 "rmse": float(np.sqrt(np.mean(d ** 2))), "max": float(np.abs(d).max()),
+                "rmse_unfiltered": float(np.sqrt(np.mean(d_unf ** 2))),
+                "max_unfiltered": float(np.abs(d_unf).max()),
+                "other_minimum_clusters": others,
                 "median_all": float(np.median(d_all[np.repeat(ok_c, n_per)])),
                 "clusters": int(len(sample)), "clusters_same_minimum": int(same_min.sum()),
                 "clusters_other_minimum": int((ok_c & ~same_min).sum()),
                 "failed_here_not_there": int(((gpu_status[sample] != 0) & (hb.status[sample] == 0)).sum()),
                 "failed_there_not_here": int(((gpu_status[sample] == 0) & (hb.status[sample] != 0)).sum()),
                 "note": "engine vs the reference algorithm with its default SLSQP tol=1e-6 "
-                        "(north_star: <= 1e-3 px); rmse/max over clusters whose cost agrees to 1e-5"}
+                        "(north_star: <= 1e-3 px); rmse/max over clusters whose cost agrees to 1e-5, "
+                        "rmse_unfiltered/max_unfiltered over all clusters both fit; every cluster that "
+                        "ends in another local minimum is listed with both costs"}
             # (b) the C oracle (same LM as the engine, scalar C + OpenMP over clusters), full workload
             base = cpu_baseline(prep.problem, prep.batch)
             both = (hb.status == 0) & (gpu_status == 0)

@@ -361,8 +361,11 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
     }
     return true;
   };
-  // cv[m], Cj[m][LDC] at vv (constraints.py:59-137); wave 0
-  auto eval_constraints = [&](const double* vv, double* cvo, double* Cjo, int* cpo) {
+  // cv[m], Cj[m][LDC] at vv (constraints.py:59-137); wave 0.  2D tetramer: the constrained
+  // pairs are the 4 smallest of the 6 pair distances; with use_fixed the pairs fixedp[0..m) are
+  // used as they are (a smooth branch of that function) instead of being ranked again.
+  auto eval_constraints = [&](const double* vv, double* cvo, double* Cjo, int* cpo, bool use_fixed,
+                              const int (&fixedp)[MAXC]) {
     if (m == 0) return;
     const int npairs = k.prob.constraint_kind == CTR_CONS_DIMER ? 1
                      : k.prob.constraint_kind == CTR_CONS_TRIMER ? 3 : 6;
@@ -388,7 +391,11 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
       double mine = 0.;
 #pragma unroll
       for (int p = 0; p < 6; ++p) if (p == q) mine = d2[p];
-      if (k.prob.constraint_kind == CTR_CONS_TETRAMER && ND == 2) {
+      if (use_fixed) {
+        rank = MAXC;
+#pragma unroll
+        for (int r = 0; r < MAXC; ++r) rank = (r < m && fixedp[r] == q) ? r : rank;
+      } else if (k.prob.constraint_kind == CTR_CONS_TETRAMER && ND == 2) {
         rank = 0;  // stable rank among the 6 squared distances (constraints.py:112)
 #pragma unroll
         for (int p = 0; p < 6; ++p) rank += (d2[p] < mine || (d2[p] == mine && p < q)) ? 1 : 0;
@@ -455,46 +462,70 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
   // Cjo / cpo describe the constraints at the returned point.
   auto retract = [&](double* x, double* cvo, double* Cjo, int* cpo) -> bool {
     double* ry = cv + 18;   // (6 free doubles of the small block)
-    for (int iter = 0; iter <= 30; ++iter) {
-      eval_constraints(x, cvo, Cjo, cpo);
-      double cmax = 0.;
-      bool nan = false;
-      for (int r = 0; r < m; ++r) { const double a = fabs(cvo[r]); nan = nan || !(a == a); cmax = fmax(cmax, a); }
-      if (nan) return false;
-      if (cmax <= 1e-13) return true;
-      if (iter == 30) break;
-      const bool isvar = lane < nv;
-      const double xi = isvar ? x[lane] : 0., li = isvar ? lo[lane] : 0., ui = isvar ? hi[lane] : 0.;
-      bool pinned = !isvar || !(li < ui);
-      double ti = 0.;
-      for (int pass = 0; pass < 2; ++pass) {
-        const unsigned long long fm = __ballot(!pinned);
-        if (lane < m * m) {
-          const int r = lane / m, s2 = lane % m;
-          double t = 0.;
-          for (unsigned long long q = fm; q != 0ull; q &= q - 1ull) {
-            const int i = __builtin_ctzll(q);
-            t += Cjo[r * LDC + i] * Cjo[s2 * LDC + i];
+    const bool ranked = k.prob.constraint_kind == CTR_CONS_TETRAMER && ND == 2;
+    int pairs[MAXC];
+#pragma unroll
+    for (int r = 0; r < MAXC; ++r) pairs[r] = 0;
+    eval_constraints(x, cvo, Cjo, cpo, false, pairs);
+#pragma unroll
+    for (int r = 0; r < MAXC; ++r) pairs[r] = r < m ? cpo[r] : 0;
+    wsync();
+    // 2D tetramer: Newton on the branch of the current pair set; if the ranking at the point
+    // reached names another set, once more on that one
+    for (int branch = 0; branch < 4; ++branch) {
+      bool conv = false;
+      for (int iter = 0; iter <= 30; ++iter) {
+        eval_constraints(x, cvo, Cjo, cpo, true, pairs);
+        double cmax = 0.;
+        bool nan = false;
+        for (int r = 0; r < m; ++r) { const double a = fabs(cvo[r]); nan = nan || !(a == a); cmax = fmax(cmax, a); }
+        if (nan) return false;
+        if (cmax <= 1e-13) { conv = true; break; }
+        if (iter == 30) break;
+        const bool isvar = lane < nv;
+        const double xi = isvar ? x[lane] : 0., li = isvar ? lo[lane] : 0., ui = isvar ? hi[lane] : 0.;
+        bool pinned = !isvar || !(li < ui);
+        double ti = 0.;
+        for (int pass = 0; pass < 2; ++pass) {
+          const unsigned long long fm = __ballot(!pinned);
+          if (lane < m * m) {
+            const int r = lane / m, s2 = lane % m;
+            double t = 0.;
+            for (unsigned long long q = fm; q != 0ull; q &= q - 1ull) {
+              const int i = __builtin_ctzll(q);
+              t += Cjo[r * LDC + i] * Cjo[s2 * LDC + i];
+            }
+            Sc[r * MAXC + s2] = t;
           }
-          Sc[r * MAXC + s2] = t;
+          if (lane < m) ry[lane] = cvo[lane];
+          wsync();
+          small_spd_solve(Sc, ry);
+          if (flag[0] == 0.) return false;
+          ti = 0.;
+          if (!pinned)
+            for (int r = 0; r < m; ++r) ti += Cjo[r * LDC + lane] * ry[r];
+          if (pass == 1) break;
+          const bool newpin = !pinned && ((xi <= li && ti > 0.) || (xi >= ui && ti < 0.));
+          if (__ballot(newpin) == 0ull) break;
+          pinned = pinned || newpin;
+          wsync();
         }
-        if (lane < m) ry[lane] = cvo[lane];
-        wsync();
-        small_spd_solve(Sc, ry);
-        if (flag[0] == 0.) return false;
-        ti = 0.;
-        if (!pinned)
-          for (int r = 0; r < m; ++r) ti += Cjo[r * LDC + lane] * ry[r];
-        if (pass == 1) break;
-        const bool newpin = !pinned && ((xi <= li && ti > 0.) || (xi >= ui && ti < 0.));
-        if (__ballot(newpin) == 0ull) break;
-        pinned = pinned || newpin;
+        if (!pinned && ti != 0.) {
+          const double t = xi - ti;
+          x[lane] = t < li ? li : (t > ui ? ui : t);
+        }
         wsync();
       }
-      if (!pinned && ti != 0.) {
-        const double t = xi - ti;
-        x[lane] = t < li ? li : (t > ui ? ui : t);
-      }
+      if (!conv) return false;
+      if (!ranked) return true;
+      eval_constraints(x, cvo, Cjo, cpo, false, pairs);
+      unsigned sa = 0u, sb = 0u;
+#pragma unroll
+      for (int r = 0; r < MAXC; ++r)
+        if (r < m) { sa |= 1u << cpo[r]; sb |= 1u << pairs[r]; }
+      if (sa == sb) return true;
+#pragma unroll
+      for (int r = 0; r < MAXC; ++r) pairs[r] = r < m ? cpo[r] : 0;
       wsync();
     }
     return false;

@@ -27,48 +27,17 @@
 #include <string>
 #include <vector>
 
-#include "ctrefine.h"
+#include "kargs.h"
 
 namespace {
 
 #include "device_common.h"
-#include "block_kernel.h"
-#include "small_kernel.h"
 #include "aux_kernels.h"
 
 // ---- host side ------------------------------------------------------------------------
 
-constexpr size_t LDS_CU = 160 * 1024;  // LDS of one CU
-
-typedef void (*kernel_fn)(const KArgs);
-typedef void (*small_fn)(const KArgs, int*);
-
-template <int NT> struct WavesFor { static constexpr int value = NT <= 2 ? 8 : (NT <= 3 ? 4 : (NT <= 6 ? 2 : 1)); };
-
-// CTR_FLAG_THROUGHPUT: fewest wavefronts per cluster (a quarter of the LDS and of the wave slots
-// for 3-4 features; two or three workgroups per CU instead of one for 5-30 features)
-template <int NT> struct WavesThroughput { static constexpr int value = NT <= 2 ? 2 : 1; };
-
-template <int ND, bool ISO, int NT, bool TP = false>
-void fill_one(kernel_fn* t, size_t* bytes, int* threads) {
-  constexpr int W = TP ? WavesThroughput<NT>::value : WavesFor<NT>::value;
-  static_assert(SmemB<NT, W>::bytes <= LDS_CU, "LDS budget of one CU");
-  t[NT - 1] = refine_block_kernel<ND, ISO, NT, W>;
-  bytes[NT - 1] = SmemB<NT, W>::bytes;
-  threads[NT - 1] = WAVE * W;
-}
-
-template <int ND, bool ISO, bool TP = false>
-void fill_table(kernel_fn* t, size_t* bytes, int* threads) {
-  fill_one<ND, ISO, 1, TP>(t, bytes, threads);
-  fill_one<ND, ISO, 2, TP>(t, bytes, threads);
-  fill_one<ND, ISO, 3, TP>(t, bytes, threads);
-  fill_one<ND, ISO, 4, TP>(t, bytes, threads);
-  fill_one<ND, ISO, 5, TP>(t, bytes, threads);
-  fill_one<ND, ISO, 6, TP>(t, bytes, threads);
-  fill_one<ND, ISO, 7, TP>(t, bytes, threads);
-  fill_one<ND, ISO, 8, TP>(t, bytes, threads);
-}
+typedef const void* kernel_fn;   // a kernel of another translation unit (kargs.h)
+typedef const void* small_fn;
 
 std::string g_create_error;
 std::mutex g_mutex;
@@ -260,28 +229,19 @@ int ctr_create(ctr_handle** out, int device) {
               hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming) == hipSuccess;
   for (auto& ev : h->ev_join) evok = evok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
   if (!evok || hipMalloc((void**)&h->d_counter, sizeof(int) * 8) != hipSuccess) { delete h; return fail(nullptr, CTR_ERR_DEVICE, "cannot create events / counters"); }
-  h->small_wide1[0][1] = refine_small_kernel<2, 1, true, 64>;
-  h->small_wide1[0][0] = refine_small_kernel<2, 1, false, 64>;
-  h->small_wide1[1][1] = refine_small_kernel<3, 1, true, 64>;
-  h->small_wide1[1][0] = refine_small_kernel<3, 1, false, 64>;
-  h->small_bulk2[0][1] = refine_small_kernel<2, 2, true, 16>;
-  h->small_bulk2[0][0] = refine_small_kernel<2, 2, false, 16>;
-  h->small_bulk2[1][1] = refine_small_kernel<3, 2, true, 16>;
-  h->small_bulk2[1][0] = refine_small_kernel<3, 2, false, 16>;
-  h->small_table[0][1][0] = refine_small_kernel<2, 1, true, 8>;
-  h->small_table[0][1][1] = refine_small_kernel<2, 2, true, 64>;
-  h->small_table[0][0][0] = refine_small_kernel<2, 1, false, 8>;
-  h->small_table[0][0][1] = refine_small_kernel<2, 2, false, 64>;
-  h->small_table[1][1][0] = refine_small_kernel<3, 1, true, 8>;
-  h->small_table[1][1][1] = refine_small_kernel<3, 2, true, 64>;
-  h->small_table[1][0][0] = refine_small_kernel<3, 1, false, 8>;
-  h->small_table[1][0][1] = refine_small_kernel<3, 2, false, 64>;
-  fill_table<2, true, true>(h->table_tp[0][1], h->smem_bytes_tp[0][1], h->block_threads_tp[0][1]);
-  fill_table<2, false, true>(h->table_tp[0][0], h->smem_bytes_tp[0][0], h->block_threads_tp[0][0]);
-  fill_table<2, true>(h->table[0][1], h->smem_bytes[0][1], h->block_threads[0][1]);
-  fill_table<2, false>(h->table[0][0], h->smem_bytes[0][0], h->block_threads[0][0]);
-  fill_table<3, true>(h->table[1][1], h->smem_bytes[1][1], h->block_threads[1][1]);
-  fill_table<3, false>(h->table[1][0], h->smem_bytes[1][0], h->block_threads[1][0]);
+  for (int di = 0; di < 2; ++di)
+    for (int ii = 0; ii < 2; ++ii) {
+      h->small_wide1[di][ii] = ctr_small_kernel(2 + di, 1, ii, 64);
+      h->small_bulk2[di][ii] = ctr_small_kernel(2 + di, 2, ii, 16);
+      h->small_table[di][ii][0] = ctr_small_kernel(2 + di, 1, ii, 8);
+      h->small_table[di][ii][1] = ctr_small_kernel(2 + di, 2, ii, 64);
+      for (int nt = 1; nt <= MAXNT; ++nt) {
+        const KernelInfo a = di == 0 ? ctr_block_kernel_2d(ii, nt, 0) : ctr_block_kernel_3d(ii, nt, 0);
+        const KernelInfo t = di == 0 ? ctr_block_kernel_2d(ii, nt, 1) : ctr_block_kernel_3d(ii, nt, 1);
+        h->table[di][ii][nt - 1] = a.fn; h->smem_bytes[di][ii][nt - 1] = a.smem; h->block_threads[di][ii][nt - 1] = a.threads;
+        h->table_tp[di][ii][nt - 1] = t.fn; h->smem_bytes_tp[di][ii][nt - 1] = t.smem; h->block_threads_tp[di][ii][nt - 1] = t.threads;
+      }
+    }
   *out = h;
   return CTR_OK;
 }
@@ -460,12 +420,15 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     const int threads = tp ? h->block_threads_tp[di][ii][bin] : h->block_threads[di][ii][bin];
     bool& attr = tp ? h->attr_set_tp[di][ii][bin] : h->attr_set[di][ii][bin];
     if (!attr) {
-      HIP_TRY(h, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
       attr = true;
     }
     k.order = ord + plan->bin_begin[bin];
     k.n_bin = (int32_t)cnt;
-    hipLaunchKernelGGL(fn, dim3((unsigned)cnt), dim3((unsigned)threads), bytes, pick_stream(false), k);
+    {
+      void* kargs[] = {(void*)&k};
+      HIP_TRY(h, hipLaunchKernel(fn, dim3((unsigned)cnt), dim3((unsigned)threads), kargs, bytes, pick_stream(false)));
+    }
   }
   if (plan->bin_count[BIN_TOO_LARGE] > 0) {
     const int64_t cnt = plan->bin_count[BIN_TOO_LARGE];
@@ -516,12 +479,18 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
       k.split_part = 2;
       int64_t wb = (cnt + 3) / 4;
       if (wb > 8192) wb = 8192;
-      hipLaunchKernelGGL(h->small_bulk2[di][ii], dim3((unsigned)wb), dim3(WAVE), 0, sb, k, cbulk);
+      {
+        void* kargs[] = {(void*)&k, (void*)&cbulk};
+        HIP_TRY(h, hipLaunchKernel(h->small_bulk2[di][ii], dim3((unsigned)wb), dim3(WAVE), kargs, 0, sb));
+      }
       k.split_part = 1;
       if (waves > 2048) waves = 2048;   // persistent: a wavefront takes pair after pair
     }
     if (waves > 8192) waves = 8192;
-    hipLaunchKernelGGL(fn, dim3((unsigned)waves), dim3(WAVE), 0, st, k, counter);
+    {
+      void* kargs[] = {(void*)&k, (void*)&counter};
+      HIP_TRY(h, hipLaunchKernel(fn, dim3((unsigned)waves), dim3(WAVE), kargs, 0, st));
+    }
     k.split = nullptr;
     k.split_part = 0;
   }
@@ -536,16 +505,6 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
   return CTR_OK;
 }
 
-#ifdef CTR_STAMPS
-int ctr_debug_stamps(unsigned long long* out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
-  if (reset) {
-    unsigned long long z[16] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z) != hipSuccess) return 1;
-  }
-  return 0;
-}
-#endif
 
 
 int ctr_find_clusters(ctr_handle* h, int32_t ndim, const double* pos, const int32_t* frame_offset,

@@ -16,33 +16,6 @@ constexpr int FP = 14;        // derived per-feature constants (see fill_fpar)
 // (relative) is reported as converged; same rule as STALL_TOL in oracle/ctr_oracle.c
 #define CTR_STALL_TOL 1e-9
 
-struct KArgs {
-  ctr_problem prob;
-  const void* frames;
-  int32_t frame_dtype;
-  int32_t n_bin;
-  int64_t shape[3];
-  int64_t frame_elems;
-  const int32_t* frame_index;
-  const int32_t* feat_offset;
-  const double* params;
-  const double* low;
-  const double* high;
-  double* params_out;
-  double* cost;
-  int32_t* status;
-  int32_t* n_rounds;
-  int32_t* n_iter;
-  double* params_std;    // [N, n_params] or nullptr (ctr_batch.params_std)
-  const double* fmax;
-  const int32_t* order;  // cluster ids of this bin
-  // small kernel only: part of the bin a launch takes.  split == nullptr: all of it;
-  // split_part 1: entries [0, *split) (the likely slow fits, front_load_kernel's count),
-  // split_part 2: entries [*split, n_bin)
-  const int32_t* split;
-  int32_t split_part;
-};
-
 __device__ __forceinline__ size_t dtype_size(int dtype) {
   return dtype == CTR_DTYPE_U8 ? 1 : (dtype == CTR_DTYPE_U16 || dtype == CTR_DTYPE_I16) ? 2
        : (dtype == CTR_DTYPE_I32 || dtype == CTR_DTYPE_F32) ? 4 : 8;

@@ -11,7 +11,10 @@ one integer per rank to keep the running cluster-id offset of the reference
 import numpy as np
 import pandas as pd
 
-from .refine import prepare_batch, write_back, _run_on_engine
+import os
+
+from . import refine as _refine
+from .refine import prepare_batch, write_back
 
 
 def frame_block(frame_numbers, world_size, rank):
@@ -26,11 +29,14 @@ def frame_block(frame_numbers, world_size, rank):
 
 
 def refine_leastsq_sharded(f, reader, diameter, group=None, device=None,
-                           t_column='frame', gather=True, _run_batch=None, **kwargs):
+                           t_column='frame', gather=True, **kwargs):
     """``refine_leastsq`` with the frames sharded over the ranks of ``group``
     (default: the world group).  ``reader`` must serve every frame this rank
     owns.  Every rank returns the full result table when ``gather`` is true
     (frame-sorted, identical on all ranks), else only its own rows.
+    ``device``: HIP device index of this process; default ``LOCAL_RANK`` (set by
+    torch.distributed.run; the rank inside the node, not the group rank), else the current
+    torch device.
     """
     import torch
     import torch.distributed as dist
@@ -48,24 +54,26 @@ def refine_leastsq_sharded(f, reader, diameter, group=None, device=None,
     options.update(kwargs.pop('options', None) or {})
     kwargs.pop('method', None)
     kwargs.pop('tol', None)
-    for key in ('noise_size', 'threshold'):
-        if kwargs.pop(key, None) is not None:
-            raise NotImplementedError("%s is not implemented by the MI355X engine" % key)
-    if kwargs.pop('compute_error', False):
-        raise NotImplementedError("compute_error is not implemented by the MI355X engine")
-    prep = prepare_batch(f_local, reader, diameter, t_column=t_column,
-                         solver_maxiter=int(options.get('maxiter', 100)), **kwargs)
-    if prep.batch.n_clusters:
-        if _run_batch is not None:
-            _run_batch(prep.problem, prep.batch)
+    if kwargs.pop('noise_size', None) is not None:
+        raise NotImplementedError("noise_size is not implemented by the MI355X engine")
+    kwargs.pop('threshold', None)     # only used together with noise_size (refine.py:37-40)
+    backend = dist.get_backend(group)
+    if device is None:
+        if 'LOCAL_RANK' in os.environ:
+            device = int(os.environ['LOCAL_RANK'])
+        elif backend == 'nccl':
+            device = torch.cuda.current_device()
         else:
-            _run_on_engine(prep.problem, prep.batch,
-                           device if device is not None else rank)
+            device = 0
+    if backend == 'nccl' and not 0 <= device < torch.cuda.device_count():
+        raise ValueError("device %d is not one of the %d visible GPUs" % (device, torch.cuda.device_count()))
+    prep = prepare_batch(f_local, reader, diameter, t_column=t_column,
+                         solver_maxiter=int(options.get('maxiter', 100)), device=device, **kwargs)
+    if prep.batch.n_clusters:
+        _refine._run_on_engine(prep.problem, prep.batch, device)
     out = write_back(prep)
 
-    backend = dist.get_backend(group)
-    dev = torch.device('cuda', device if device is not None else rank) \
-        if backend == 'nccl' else torch.device('cpu')
+    dev = torch.device('cuda', device) if backend == 'nccl' else torch.device('cpu')
 
     # running cluster-id offset: ids of a frame start where the previous frame's ended
     next_id = int(out['cluster'].max()) + 1 if len(out) else 0

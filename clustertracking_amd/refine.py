@@ -240,7 +240,6 @@ def refine_leastsq(f, reader, diameter, separation=None, fit_function='gauss',
     ftol = kwargs.pop('ftol', 0.)
     device = kwargs.pop('device', 0)
     cluster_labels = kwargs.pop('cluster_labels', 'reference')
-    run_batch = kwargs.pop('_run_batch', None)  # test hook (oracle on CPU)
     if kwargs:
         raise TypeError("unexpected keyword arguments: %s" % sorted(kwargs))
     if noise_size is not None:
@@ -255,8 +254,5 @@ def refine_leastsq(f, reader, diameter, separation=None, fit_function='gauss',
                          xtol=xtol, ftol=ftol, cluster_labels=cluster_labels, device=device,
                          compute_error=compute_error)
     if prep.batch.n_clusters:
-        if run_batch is None:
-            _run_on_engine(prep.problem, prep.batch, device)
-        else:
-            run_batch(prep.problem, prep.batch)
+        _run_on_engine(prep.problem, prep.batch, device)
     return write_back(prep)

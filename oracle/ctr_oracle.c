@@ -191,8 +191,11 @@ static int n_constraints(const ctr_problem* p, int n) {
   }
 }
 
-/* c[m] and Jacobian Cj[m][nv] at v */
-static void eval_constraints(const ctx_t* c, const double* v, double* cv, double* Cj, int* pair_of) {
+/* c[m] and Jacobian Cj[m][nv] at v.  2D tetramer: the constrained pairs are the 4 smallest of
+ * the 6 pair distances (constraints.py:102-114); with use_pairs != NULL those pairs are used
+ * as they are (a smooth branch of that function) instead of being ranked again. */
+static void eval_constraints(const ctx_t* c, const double* v, double* cv, double* Cj, int* pair_of,
+                             const int* use_pairs) {
   const int nd = c->L.nd, nv = c->L.nv, m = c->n_cons;
   int npairs = c->p->constraint_kind == CTR_CONS_DIMER ? 1
              : c->p->constraint_kind == CTR_CONS_TRIMER ? 3 : 6;
@@ -209,7 +212,9 @@ static void eval_constraints(const ctx_t* c, const double* v, double* cv, double
     d2[q] = s;
     order[q] = q;
   }
-  if (c->p->constraint_kind == CTR_CONS_TETRAMER && nd == 2) {
+  if (use_pairs) {
+    for (int r = 0; r < m; ++r) order[r] = use_pairs[r];
+  } else if (c->p->constraint_kind == CTR_CONS_TETRAMER && nd == 2) {
     /* the 4 smallest of the 6 pair distances (constraints.py:102-114) */
     for (int i = 1; i < 6; ++i) {
       int o = order[i], j = i - 1;
@@ -429,53 +434,71 @@ typedef struct { double S; long P; int iters; int ok; } solve_t;
  * at the returned point.  0: no convergence (degenerate geometry, or the box is in the way). */
 #define RETRACT_MAXIT 30
 #define RETRACT_TOL 1e-13
+static int same_pair_set(const int* a, const int* b, int m) {
+  unsigned sa = 0, sb = 0;
+  for (int r = 0; r < m; ++r) { sa |= 1u << a[r]; sb |= 1u << b[r]; }
+  return sa == sb;
+}
+
 static int retract(const ctx_t* c, double* x, const double* lo, const double* hi,
                    double* cv, double* Cj, int* pair_of) {
   const int nv = c->L.nv, m = c->n_cons;
+  const int ranked = c->p->constraint_kind == CTR_CONS_TETRAMER && c->L.nd == 2;
   double G[MAXC * MAXC], y[MAXC];
-  int pinned[MAXV];
-  for (int iter = 0; iter <= RETRACT_MAXIT; ++iter) {
-    double cmax = 0.;
-    eval_constraints(c, x, cv, Cj, pair_of);
-    for (int r = 0; r < m; ++r) if (fabs(cv[r]) > cmax) cmax = fabs(cv[r]);
-    if (!(cmax == cmax)) return 0;
-    if (cmax <= RETRACT_TOL) return 1;
-    if (iter == RETRACT_MAXIT) break;
-    /* pass 0: all variables the box does not fix; a variable ON a bound that this correction
-     * would push outward is pinned and the correction recomputed without it (pass 1) */
-    for (int i = 0; i < nv; ++i) pinned[i] = !(lo[i] < hi[i]);
-    for (int pass = 0; pass < 2; ++pass) {
-      double tr = 0.;
-      int changed = 0;
-      for (int r = 0; r < m; ++r)
-        for (int s = 0; s <= r; ++s) {
+  int pinned[MAXV], pairs[MAXC];
+  eval_constraints(c, x, cv, Cj, pairs, NULL);
+  /* 2D tetramer: Newton on the branch of the current pair set; if the ranking at the point
+   * reached names another set, once more on that one */
+  for (int branch = 0; branch < 4; ++branch) {
+    int converged = 0;
+    for (int iter = 0; iter <= RETRACT_MAXIT && !converged; ++iter) {
+      double cmax = 0.;
+      eval_constraints(c, x, cv, Cj, pair_of, pairs);
+      for (int r = 0; r < m; ++r) if (fabs(cv[r]) > cmax) cmax = fabs(cv[r]);
+      if (!(cmax == cmax)) return 0;
+      if (cmax <= RETRACT_TOL) { converged = 1; break; }
+      if (iter == RETRACT_MAXIT) break;
+      /* pass 0: all variables the box does not fix; a variable ON a bound that this correction
+       * would push outward is pinned and the correction recomputed without it (pass 1) */
+      for (int i = 0; i < nv; ++i) pinned[i] = !(lo[i] < hi[i]);
+      for (int pass = 0; pass < 2; ++pass) {
+        double tr = 0.;
+        int changed = 0;
+        for (int r = 0; r < m; ++r)
+          for (int s = 0; s <= r; ++s) {
+            double t = 0.;
+            for (int i = 0; i < nv; ++i)
+              if (!pinned[i]) t += Cj[r * nv + i] * Cj[s * nv + i];
+            G[r * m + s] = t;
+            if (r == s) tr += t;
+          }
+        if (!(tr > 0.)) return 0;
+        for (int r = 0; r < m; ++r) { G[r * m + r] += 1e-14 * tr + 1e-300; y[r] = cv[r]; }
+        if (!cholesky(G, m, m)) return 0;
+        chol_solve(G, m, m, y);
+        if (pass == 1) break;
+        for (int i = 0; i < nv; ++i) {
+          if (pinned[i]) continue;
           double t = 0.;
-          for (int i = 0; i < nv; ++i)
-            if (!pinned[i]) t += Cj[r * nv + i] * Cj[s * nv + i];
-          G[r * m + s] = t;
-          if (r == s) tr += t;
+          for (int r = 0; r < m; ++r) t += Cj[r * nv + i] * y[r];
+          if ((x[i] <= lo[i] && t > 0.) || (x[i] >= hi[i] && t < 0.)) { pinned[i] = 1; changed = 1; }
         }
-      if (!(tr > 0.)) return 0;
-      for (int r = 0; r < m; ++r) { G[r * m + r] += 1e-14 * tr + 1e-300; y[r] = cv[r]; }
-      if (!cholesky(G, m, m)) return 0;
-      chol_solve(G, m, m, y);
-      if (pass == 1) break;
+        if (!changed) break;
+      }
       for (int i = 0; i < nv; ++i) {
         if (pinned[i]) continue;
         double t = 0.;
         for (int r = 0; r < m; ++r) t += Cj[r * nv + i] * y[r];
-        if ((x[i] <= lo[i] && t > 0.) || (x[i] >= hi[i] && t < 0.)) { pinned[i] = 1; changed = 1; }
+        if (t == 0.) continue;
+        t = x[i] - t;
+        x[i] = t < lo[i] ? lo[i] : (t > hi[i] ? hi[i] : t);
       }
-      if (!changed) break;
     }
-    for (int i = 0; i < nv; ++i) {
-      if (pinned[i]) continue;
-      double t = 0.;
-      for (int r = 0; r < m; ++r) t += Cj[r * nv + i] * y[r];
-      if (t == 0.) continue;
-      t = x[i] - t;
-      x[i] = t < lo[i] ? lo[i] : (t > hi[i] ? hi[i] : t);
-    }
+    if (!converged) return 0;
+    if (!ranked) return 1;
+    eval_constraints(c, x, cv, Cj, pair_of, NULL);
+    if (same_pair_set(pair_of, pairs, m)) return 1;
+    memcpy(pairs, pair_of, sizeof(int) * (size_t)m);
   }
   return 0;
 }

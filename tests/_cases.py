@@ -62,9 +62,41 @@ class Case(object):
     def run(self, run_batch=None):
         """refine_leastsq through the host layer; run_batch=None -> HIP engine."""
         diameter, kw = self.kwargs()
-        if run_batch is not None:
-            kw['_run_batch'] = run_batch
-        return cta.refine_leastsq(self.f0.copy(), self.reader(), diameter, **kw)
+        return refine_leastsq(self.f0.copy(), self.reader(), diameter, _run_batch=run_batch, **kw)
+
+
+class engine_replaced_by(object):
+    """Context manager for the CPU tests: the one call of the host layer that reaches the HIP
+    engine (clustertracking_amd.refine._run_on_engine) runs ``run_batch(problem, batch)``
+    instead (the C oracle).  The product has no such switch."""
+
+    def __init__(self, run_batch):
+        self.run_batch = run_batch
+
+    def __enter__(self):
+        from clustertracking_amd import refine as _r
+        self._saved = _r._run_on_engine
+        if self.run_batch is not None:
+            rb = self.run_batch
+            _r._run_on_engine = lambda problem, batch, device=0: rb(problem, batch)
+        return self
+
+    def __exit__(self, *exc):
+        from clustertracking_amd import refine as _r
+        _r._run_on_engine = self._saved
+        return False
+
+
+def refine_leastsq(*args, **kwargs):
+    """cta.refine_leastsq, with ``_run_batch`` (None = the HIP engine) in place of the engine."""
+    with engine_replaced_by(kwargs.pop('_run_batch', None)):
+        return cta.refine_leastsq(*args, **kwargs)
+
+
+def refine_leastsq_sharded(*args, **kwargs):
+    from clustertracking_amd import parallel
+    with engine_replaced_by(kwargs.pop('_run_batch', None)):
+        return parallel.refine_leastsq_sharded(*args, **kwargs)
 
 
 def is_solver_specific(name):
@@ -113,7 +145,7 @@ def check_solver_specific(name, res, A, B, pos_columns):
         if cb == cb and abs(co - cb) <= 1e-7 * cb:
             d = np.abs(g[pos_columns].values - b[pos_columns].values).max()
             assert d < 5e-6, (name, cl, 'vs B', d)
-        elif ca == ca and abs(co - ca) <= 1e-3 * ca:
+        elif ca == ca and abs(co - ca) <= 1e-4 * ca:
             d = np.abs(g[pos_columns].values - a[pos_columns].values).max()
             assert d < 1e-2, (name, cl, 'vs A', d)
     return n_checked

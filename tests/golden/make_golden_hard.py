@@ -56,7 +56,9 @@ def tetramer2d():
         for gx in range(3):
             c = np.array([45. + gy * 80, 45. + gx * 80]) + rng.uniform(-.5, .5, 2)
             a = rng.uniform(0, 2 * np.pi)
-            shear = rng.uniform(np.pi / 3, np.pi / 2)       # rhombus angle
+            # rhombus angle; well away from 60 degrees, where the short diagonal equals the bond
+            # length and the reference's sort-based constraint function has a kink
+            shear = rng.uniform(np.pi * 5 / 12, np.pi / 2)
             e1 = np.array([np.sin(a), np.cos(a)]) * 2 * size
             e2 = np.array([np.sin(a + shear), np.cos(a + shear)]) * 2 * size
             truth += [c, c + e1, c + e1 + e2, c + e2]

@@ -120,26 +120,26 @@ def test_unsupported_is_loud(oracle):
                dict(compute_error=True, param_mode=dict(signal='cluster')),
                dict(fit_function=dict(params=[], func=None))):
         with pytest.raises(NotImplementedError):
-            cta.refine_leastsq(f0.copy(), im, 13, _run_batch=run, **kw)
+            _cases.refine_leastsq(f0.copy(), im, 13, _run_batch=run, **kw)
     with pytest.raises(ValueError):
-        cta.refine_leastsq(f0.copy(), im, 13, fit_function='nonsense', _run_batch=run)
+        _cases.refine_leastsq(f0.copy(), im, 13, fit_function='nonsense', _run_batch=run)
     with pytest.raises(ValueError):
-        cta.refine_leastsq(f0.copy(), im, 13, max_iter=0, _run_batch=run)
+        _cases.refine_leastsq(f0.copy(), im, 13, max_iter=0, _run_batch=run)
     with pytest.raises(TypeError):
-        cta.refine_leastsq(f0.copy(), im, 13, bogus=1, _run_batch=run)
+        _cases.refine_leastsq(f0.copy(), im, 13, bogus=1, _run_batch=run)
     with pytest.raises(NotImplementedError):
         constraints.dimer_global(1.)
     with pytest.raises(NotImplementedError):
-        cta.refine_leastsq(f0.copy(), im, 13, _run_batch=run,
+        _cases.refine_leastsq(f0.copy(), im, 13, _run_batch=run,
                            constraints=constraints.dimer(6.) + constraints.trimer(6.))
     with pytest.raises(NotImplementedError):
-        cta.refine_leastsq(f0.copy(), im, 13, _run_batch=run,
+        _cases.refine_leastsq(f0.copy(), im, 13, _run_batch=run,
                            constraints=[dict(type='eq', fun=lambda x: 0., cluster_size=2)])
     with pytest.raises(ValueError):   # SciPy: lower bound exceeds upper bound
-        cta.refine_leastsq(f0.copy(), im, 13, _run_batch=run, bounds=dict(signal=(500, 1000),
+        _cases.refine_leastsq(f0.copy(), im, 13, _run_batch=run, bounds=dict(signal=(500, 1000),
                            signal_rel_diff=0.1))
     with pytest.raises(AssertionError):
-        cta.refine_leastsq(f0.copy(), np.zeros((4, 8, 8)), 13, _run_batch=run)
+        _cases.refine_leastsq(f0.copy(), np.zeros((4, 8, 8)), 13, _run_batch=run)
 
 
 def test_side_effects_and_output_shape(oracle):
@@ -148,7 +148,7 @@ def test_side_effects_and_output_shape(oracle):
     im, truth, f0 = small_problem()
     f0 = f0.drop(columns=['background'])
     f_in = f0.copy()
-    res = cta.refine_leastsq(f_in, im, 13, _run_batch=_cases.oracle_runner())
+    res = _cases.refine_leastsq(f_in, im, 13, _run_batch=_cases.oracle_runner())
     assert 'frame' in f_in and (f_in['frame'] == 0).all()
     assert_equal(f_in[['y', 'x']].values, f0[['y', 'x']].values)   # input rows untouched
     for col in ('cluster', 'cluster_size', 'background', 'cost', 'frame'):
@@ -158,7 +158,7 @@ def test_side_effects_and_output_shape(oracle):
     d = res[['y', 'x']].values - truth
     assert np.sqrt(np.mean(d ** 2)) < 0.1
     # accepted-and-ignored SciPy kwargs
-    res2 = cta.refine_leastsq(f0.copy(), im, 13, method='SLSQP', tol=1e-6,
+    res2 = _cases.refine_leastsq(f0.copy(), im, 13, method='SLSQP', tol=1e-6,
                               options=dict(maxiter=100, disp=False),
                               _run_batch=_cases.oracle_runner())
     assert_allclose(res2[['y', 'x']].values, res[['y', 'x']].values, atol=1e-12)
@@ -171,7 +171,7 @@ def test_frame_no_attribute_and_video_order(oracle):
     im, truth, f0 = small_problem(3)
     fr = im.view(Frame)
     fr.frame_no = 7
-    res = cta.refine_leastsq(f0.copy(), fr, 13, _run_batch=_cases.oracle_runner())
+    res = _cases.refine_leastsq(f0.copy(), fr, 13, _run_batch=_cases.oracle_runner())
     assert (res['frame'] == 7).all()
     # rows of a two-frame video come back grouped by frame (find.py:157)
     im2, truth2, f2 = small_problem(4)
@@ -180,9 +180,9 @@ def test_frame_no_attribute_and_video_order(oracle):
     f0b['frame'] = 0
     video = cta.ArrayReader(np.stack([im2, im]))
     both = pd.concat([f0a, f0b], ignore_index=True)
-    res = cta.refine_leastsq(both, video, 13, _run_batch=_cases.oracle_runner())
+    res = _cases.refine_leastsq(both, video, 13, _run_batch=_cases.oracle_runner())
     assert_equal(res['frame'].values, np.sort(both['frame'].values))
-    single = cta.refine_leastsq(f0.copy(), im, 13, _run_batch=_cases.oracle_runner())
+    single = _cases.refine_leastsq(f0.copy(), im, 13, _run_batch=_cases.oracle_runner())
     sub = res[res['frame'] == 1]
     assert_allclose(sub[['y', 'x']].values, single[['y', 'x']].values, atol=1e-12)
     # cluster ids keep running across frames (find.py:120-128)
@@ -210,7 +210,7 @@ def test_accuracy_vs_truth_like_reference_suite(oracle):
         f0['signal'] = float(signal)
         f0['size'] = size
         f0['background'] = noise / 2.
-        res = cta.refine_leastsq(f0, im, 16, _run_batch=_cases.oracle_runner())
+        res = _cases.refine_leastsq(f0, im, 16, _run_batch=_cases.oracle_runner())
         assert not np.isnan(res['cost']).any()
         rms = np.sqrt(np.mean((res[['y', 'x']].values - pos) ** 2))
         assert rms < tol, (noise, rms)

@@ -47,8 +47,8 @@ def _worker(rank, world, port, out_dir):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     frames, f0 = _video()
-    res = parallel.refine_leastsq_sharded(f0, cta.ArrayReader(frames), 13,
-                                          _run_batch=_cases.oracle_runner())
+    res = _cases.refine_leastsq_sharded(f0, cta.ArrayReader(frames), 13,
+                                        _run_batch=_cases.oracle_runner())
     res.to_pickle(os.path.join(out_dir, 'rank%d.pkl' % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -62,7 +62,7 @@ def test_two_rank_gloo_matches_single_process(tmp_path, oracle):
     world = 2
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     frames, f0 = _video()
-    single = cta.refine_leastsq(f0.copy(), cta.ArrayReader(frames), 13,
+    single = _cases.refine_leastsq(f0.copy(), cta.ArrayReader(frames), 13,
                                 _run_batch=_cases.oracle_runner())
     for rank in range(world):
         got = pd.read_pickle(os.path.join(str(tmp_path), 'rank%d.pkl' % rank))

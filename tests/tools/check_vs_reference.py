@@ -30,7 +30,7 @@ for seed in range(first, first + n):
         except Exception as e:
             print('seed %d: reference raised %s' % (seed, type(e).__name__))
             continue
-    ours = cta.refine_leastsq(f0.copy(), im, diameter, _run_batch=_cases.oracle_runner(), **kw)
+    ours = _cases.refine_leastsq(f0.copy(), im, diameter, _run_batch=_cases.oracle_runner(), **kw)
     pc = ['z', 'y', 'x'][-im.ndim:]
     nan_r, nan_o = np.isnan(ref['cost'].values), np.isnan(ours['cost'].values)
     both = ~nan_r & ~nan_o
