@@ -44,9 +44,11 @@ std::mutex g_mutex;
 
 }  // namespace
 
-// bins: 0..MAXNT-1 generic kernel by NT-1; MAXNT = too large for the engine;
-// MAXNT+1 / MAXNT+2 = singles / pairs with default modes (small kernel)
-constexpr int BIN_TOO_LARGE = MAXNT, BIN_SMALL1 = MAXNT + 1, BIN_SMALL2 = MAXNT + 2, NBINS = MAXNT + 3;
+// bins: 0..MAXNT-1 generic kernel by NT-1; MAXNT = beyond the engine (see CTR_STATUS_TOO_LARGE);
+// MAXNT+1 / MAXNT+2 = singles / pairs with default modes (small kernel); MAXNT+3 = large
+// clusters (more than MAXF features or 16 MAXNT columns: refine_large_kernel)
+constexpr int BIN_TOO_LARGE = MAXNT, BIN_SMALL1 = MAXNT + 1, BIN_SMALL2 = MAXNT + 2, BIN_LARGE = MAXNT + 3,
+              NBINS = MAXNT + 4;
 static_assert(NBINS <= 16, "FrontArgs (aux_kernels.h) holds 16 bins");
 constexpr int NSIDE = 4;  // side streams for concurrent bin launches
 constexpr int GATE_US = 20;  // head start of the block kernels over the small kernels (delay_kernel)
@@ -57,6 +59,10 @@ struct ctr_plan {
   int device = 0;
   int32_t* d_order = nullptr;  // all bins back to back; second copy [n_clusters..2n): the order of one call
   int* d_front = nullptr;      // 2 * NBINS counters of front_load_kernel
+  // large clusters: workspace in HBM (kargs.h:large_ws) and where each cluster's part begins.
+  // The workspace belongs to the plan: calls that use one plan must not overlap in time.
+  double* d_ws = nullptr;
+  long long* d_ws_off = nullptr;   // [n_clusters] offset in doubles (0 for the other clusters)
   int64_t bin_begin[NBINS + 1] = {0};
   int64_t bin_count[NBINS] = {0};
 };
@@ -84,6 +90,9 @@ struct ctr_handle {
   small_fn small_table[2][2][2];  // [ndim-2][iso][nf-1]; singles with 8 lanes per cluster (eight per wavefront)
   small_fn small_wide1[2][2];     // singles with 64 lanes per cluster (large windows)
   small_fn small_bulk2[2][2];     // pairs with 16 lanes per cluster (the bulk of a pairs bin)
+  KernelInfo large[2][2];         // refine_large_kernel<ndim, iso>
+  bool large_attr[2][2] = {};
+  hipEvent_t ev_done = nullptr;   // end of the last ctr_refine_batch_device call of this handle
   hipStream_t side[NSIDE] = {};
   hipEvent_t ev_fork = nullptr, ev_gate = nullptr, ev_order = nullptr, ev_join[NSIDE] = {};
   int* d_counter = nullptr;       // work counters of the small-kernel launches
@@ -228,6 +237,7 @@ int ctr_create(ctr_handle** out, int device) {
               hipEventCreateWithFlags(&h->ev_gate, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming) == hipSuccess;
   for (auto& ev : h->ev_join) evok = evok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+  evok = evok && hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) == hipSuccess;
   if (!evok || hipMalloc((void**)&h->d_counter, sizeof(int) * 8) != hipSuccess) { delete h; return fail(nullptr, CTR_ERR_DEVICE, "cannot create events / counters"); }
   for (int di = 0; di < 2; ++di)
     for (int ii = 0; ii < 2; ++ii) {
@@ -235,6 +245,7 @@ int ctr_create(ctr_handle** out, int device) {
       h->small_bulk2[di][ii] = ctr_small_kernel(2 + di, 2, ii, 16);
       h->small_table[di][ii][0] = ctr_small_kernel(2 + di, 1, ii, 8);
       h->small_table[di][ii][1] = ctr_small_kernel(2 + di, 2, ii, 64);
+      h->large[di][ii] = ctr_large_kernel(2 + di, ii);
       for (int nt = 1; nt <= MAXNT; ++nt) {
         const KernelInfo a = di == 0 ? ctr_block_kernel_2d(ii, nt, 0) : ctr_block_kernel_3d(ii, nt, 0);
         const KernelInfo t = di == 0 ? ctr_block_kernel_2d(ii, nt, 1) : ctr_block_kernel_3d(ii, nt, 1);
@@ -258,6 +269,7 @@ void ctr_destroy(ctr_handle* h) {
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_gate) (void)hipEventDestroy(h->ev_gate);
   if (h->ev_order) (void)hipEventDestroy(h->ev_order);
+  if (h->ev_done) (void)hipEventDestroy(h->ev_done);
   for (auto& ev : h->ev_join) if (ev) (void)hipEventDestroy(ev);
   if (h->d_counter) (void)hipFree(h->d_counter);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -282,19 +294,35 @@ int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
   bool default_modes = p->modes[0] == CTR_MODE_CLUSTER && p->modes[1] == CTR_MODE_VAR;
   for (int a = 0; a < p->ndim; ++a) default_modes = default_modes && p->modes[2 + a] == CTR_MODE_VAR;
   for (int k2 = 2 + p->ndim; k2 < p->n_params; ++k2) default_modes = default_modes && p->modes[k2] == CTR_MODE_CONST;
+  int npf = 0, nsh = 0;   // per-feature / shared variables
+  for (int k2 = 0; k2 < p->n_params; ++k2) {
+    if (p->modes[k2] == CTR_MODE_VAR) ++npf;
+    else if (p->modes[k2] != CTR_MODE_CONST) ++nsh;
+  }
+  std::vector<long long> ws_off((size_t)n_clusters, 0);
+  long long ws_total = 0;
   for (int64_t c = 0; c < n_clusters; ++c) {
     const int64_t n = (int64_t)feat_offset_host[c + 1] - feat_offset_host[c];
     if (n < 0) { delete plan; return fail(h, CTR_ERR_INVALID, "feat_offset must be non-decreasing"); }
     int bin;
     const bool constrained = (p->constraint_kind == CTR_CONS_DIMER && n == 2);
-    if (n > MAXF) bin = BIN_TOO_LARGE;
+    if (n > 0x3fffffLL) bin = BIN_TOO_LARGE;
+    else if (n > MAXF) bin = BIN_LARGE;
     else if (default_modes && n == 1) bin = BIN_SMALL1;
     else if (default_modes && n == 2 && !constrained) bin = BIN_SMALL2;
     else {
       const int nv = n_vars(p, (int)n);
       const int nt = (nv + 1 + 15) / 16;
-      bin = nt > MAXNT ? BIN_TOO_LARGE : (nt < 1 ? 0 : nt - 1);
-      if (bin < MAXNT && n > (16 * (bin + 1) < MAXF ? 16 * (bin + 1) : MAXF)) bin = BIN_TOO_LARGE;
+      bin = nt > MAXNT ? BIN_LARGE : (nt < 1 ? 0 : nt - 1);
+      if (bin < MAXNT && n > (16 * (bin + 1) < MAXF ? 16 * (bin + 1) : MAXF)) bin = BIN_LARGE;
+    }
+    if (bin == BIN_LARGE) {
+      // the large kernel's 16-column row: [r, shared.., own.., r_o, shared_o..]
+      if (npf < 1 || 2 + 2 * nsh + npf > 16) bin = BIN_TOO_LARGE;
+      else {
+        ws_off[(size_t)c] = ws_total;
+        ws_total += large_ws((int)n, npf, nsh).total;
+      }
     }
     bin_of[(size_t)c] = bin;
     plan->bin_count[bin]++;
@@ -324,6 +352,17 @@ int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
       ctr_plan_destroy(plan);
       return fail(h, CTR_ERR_DEVICE, "cannot upload the plan");
     }
+    if (ws_total > 0) {
+      if (hipMalloc((void**)&plan->d_ws, sizeof(double) * (size_t)ws_total) != hipSuccess ||
+          hipMalloc((void**)&plan->d_ws_off, sizeof(long long) * (size_t)n_clusters) != hipSuccess) {
+        ctr_plan_destroy(plan);
+        return fail(h, CTR_ERR_NOMEM, "cannot allocate the workspace of the large clusters on the device");
+      }
+      if (hipMemcpy(plan->d_ws_off, ws_off.data(), sizeof(long long) * (size_t)n_clusters, hipMemcpyHostToDevice) != hipSuccess) {
+        ctr_plan_destroy(plan);
+        return fail(h, CTR_ERR_DEVICE, "cannot upload the plan");
+      }
+    }
   }
   *out = plan;
   return CTR_OK;
@@ -333,6 +372,8 @@ void ctr_plan_destroy(ctr_plan* plan) {
   if (!plan) return;
   if (plan->d_order) { (void)hipSetDevice(plan->device); (void)hipFree(plan->d_order); }
   if (plan->d_front) (void)hipFree(plan->d_front);
+  if (plan->d_ws) (void)hipFree(plan->d_ws);
+  if (plan->d_ws_off) (void)hipFree(plan->d_ws_off);
   delete plan;
 }
 
@@ -356,6 +397,9 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
   int64_t frame_elems = 1;
   for (int a = 0; a < p.ndim; ++a) frame_elems *= b->shape[a];
   h->ev_valid = false;
+  // The handle owns scratch that a call uses from start to end (frame maxima, work counters,
+  // side streams): a call on another stream waits for the previous call of this handle.
+  HIP_TRY(h, hipStreamWaitEvent(s, h->ev_done, 0));
   HIP_TRY(h, hipEventRecord(h->ev[0], s));
   int rc = ensure_fmax(h, b->n_frames > 0 ? b->n_frames : 1);
   if (rc) return rc;
@@ -430,6 +474,21 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
       HIP_TRY(h, hipLaunchKernel(fn, dim3((unsigned)cnt), dim3((unsigned)threads), kargs, bytes, pick_stream(false)));
     }
   }
+  if (plan->bin_count[BIN_LARGE] > 0) {
+    // one 1024-thread workgroup per cluster, all of a CU's LDS: first in the queue
+    const int64_t cnt = plan->bin_count[BIN_LARGE];
+    const KernelInfo& ki = h->large[di][ii];
+    if (!h->large_attr[di][ii]) {
+      HIP_TRY(h, hipFuncSetAttribute(ki.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ki.smem));
+      h->large_attr[di][ii] = true;
+    }
+    k.order = ord + plan->bin_begin[BIN_LARGE];
+    k.n_bin = (int32_t)cnt;
+    double* wsp = plan->d_ws;
+    const long long* wso = plan->d_ws_off;
+    void* kargs[] = {(void*)&k, (void*)&wsp, (void*)&wso};
+    HIP_TRY(h, hipLaunchKernel(ki.fn, dim3((unsigned)cnt), dim3((unsigned)ki.threads), kargs, ki.smem, pick_stream(false)));
+  }
   if (plan->bin_count[BIN_TOO_LARGE] > 0) {
     const int64_t cnt = plan->bin_count[BIN_TOO_LARGE];
     k.order = ord + plan->bin_begin[BIN_TOO_LARGE];
@@ -440,6 +499,7 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
   // the small kernels start a little later than the block kernels (see delay_kernel)
   bool gate = false;
   for (int bin = 0; bin < MAXNT; ++bin) gate = gate || plan->bin_count[bin] > 0;
+  gate = gate || plan->bin_count[BIN_LARGE] > 0;
   if (gate) {
     hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(WAVE), 0, s, (unsigned long long)GATE_US * 100ull);
     HIP_TRY(h, hipEventRecord(h->ev_gate, s));
@@ -501,6 +561,7 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     }
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipEventRecord(h->ev[2], s));
+  HIP_TRY(h, hipEventRecord(h->ev_done, s));
   h->ev_valid = true;
   return CTR_OK;
 }

@@ -46,10 +46,40 @@ struct KernelInfo {
   int threads;
 };
 
+// ---- workspace of one large cluster (large_kernel.h), in doubles ---------------------------
+constexpr int LARGE_MAXNB = 32;   // neighbours (features with overlapping mask boxes) per feature
+
+struct LargeWs {
+  long long nvp, nvp_i;   // variables / features rounded up to a multiple of 8
+  long long o_vec, o_cur, o_mco, o_fpar, o_pre, o_uq, o_tile, o_off, o_int, total;
+};
+
+// n features, npf per-feature and ns shared variables
+__host__ __device__ inline LargeWs large_ws(int n, int npf, int ns) {
+  LargeWs W;
+  const long long nn = n, nv = ns + nn * npf;
+  W.nvp = (nv + 7) & ~7LL;
+  W.nvp_i = (nn + 7) & ~7LL;
+  long long o = 0;
+  W.o_vec = o;  o += 14 * W.nvp;                 // v vt v0 lo hi g x r z p Ap dl Dm free
+  W.o_cur = o;  o += W.nvp_i * 8;                // parameter rows (CTR_MAX_PARAMS)
+  W.o_mco = o;  o += W.nvp_i * 3 + 8;            // mask centres
+  W.o_fpar = o; o += W.nvp_i * 14;               // derived per-feature constants (FP)
+  W.o_pre = o;  o += W.nvp_i * 32;               // factors of the diagonal blocks
+  W.o_uq = o;   o += W.nvp_i * 16;               // second-order entries + raw sums
+  W.o_tile = o; o += 2 * nn * 256;               // accepted / trial 16 x 16 tiles
+  W.o_off = o;  o += 2 * nn * LARGE_MAXNB * 64;  // accepted / trial neighbour blocks
+  W.o_int = o;  o += (W.nvp_i + 2 * nn * LARGE_MAXNB + 1) / 2 + 8;   // nbcnt, nbidx, rev (int32)
+  W.total = (o + 31) & ~31LL;
+  return W;
+}
+
+// refine_large_kernel<ND, ISO>(KArgs, double* ws, const long long* ws_off_of_cluster)
 // refine_block_kernel<ND, ISO, NT, W>: nt = 1..8; throughput != 0: the fewest wavefronts
 KernelInfo ctr_block_kernel_2d(int iso, int nt, int throughput);
 KernelInfo ctr_block_kernel_3d(int iso, int nt, int throughput);
 // refine_small_kernel<ND, NF, ISO, SG>(KArgs, int* counter); nullptr if not instantiated
 const void* ctr_small_kernel(int ndim, int nf, int iso, int sg);
+KernelInfo ctr_large_kernel(int ndim, int iso);
 
 #endif  // CTREFINE_KARGS_H

@@ -1,0 +1,991 @@
+// large_kernel.h -- refine_large_kernel: clusters beyond the block kernel (> 64 features or
+// > 127 variables), one 1024-thread workgroup per cluster, the normal matrix block-sparse in HBM/L2.
+// Part of the MI355X cluster-refinement engine; included by tu_large.hip inside its anonymous
+// namespace (device code only, gfx950).
+//
+// The reference hands a cluster of any size to SLSQP (refine.py:343-375).  A cluster of n
+// features has nv = NS + n NPF variables (NS shared: background and any 'cluster'-mode column;
+// NPF per feature), and its Gauss-Newton matrix J^T J is block sparse: the residual is a sum over
+// the features, so two features couple only where their masks overlap (plus the dense rows of
+// the shared variables).  Stored per feature in the cluster's workspace (kargs.h:large_ws):
+//   tile[i]   16 x 16: [r, shared.., own.., r_o, shared_o..]^T [same] summed over the pixels of
+//             mask i -- own x own = diagonal block, own x r = gradient, own x shared = coupling;
+//             the "_o" columns are multiplied by [i is the lowest feature covering the pixel],
+//             so that their sums over i count every union pixel once: S, P, shared x shared
+//   off[i][s] NPF x NPF: d_i d_j^T over mask i & mask j for the s-th neighbour j of i
+// both from Jacobian rows staged in LDS and contracted with v_mfma_f64_16x16x4_f64, one
+// wavefront per feature, no atomics (bitwise reproducible).  The bounded Levenberg-Marquardt
+// iteration is that of the other kernels (oracle solve(), m = 0); the linear system is solved by
+// conjugate gradients preconditioned with the factored diagonal blocks (the oracle factors the
+// dense matrix: same minimiser, iteration counts may differ).
+#ifndef CTREFINE_LARGE_KERNEL_H
+#define CTREFINE_LARGE_KERNEL_H
+
+constexpr int LW = 16;             // wavefronts per workgroup
+constexpr int LT = LW * WAVE;      // threads
+constexpr int LRS = 17;            // row stride of a wave's LDS tile (odd: conflict-free ds_write_b64)
+constexpr int LRED = 12;           // values per wave in the reduction scratch
+constexpr int LQT = 9;             // second-order entries per feature (block_kernel.h: QT)
+
+struct SmemL {
+  static constexpr int o_rows = 0;                       // LW row tiles of 64 x LRS
+  static constexpr int o_red = o_rows + LW * WAVE * LRS; // reduction scratch [LW][LRED]
+  static constexpr int o_tot = o_red + LW * LRED;        // 256 sums over the features of the tiles
+  static constexpr int o_sh = o_tot + 256;               // shared-variable scratch: 8 x 8 + 6 x 8
+  static constexpr int total = o_sh + 64 + 48;
+  static constexpr size_t bytes = (size_t)total * sizeof(double);
+};
+
+// all-threads sum of up to LRED values (in place); two workgroup barriers
+__device__ __forceinline__ void wg_sum(double* vals, int nvals, double* red, int lane, int wave) {
+  for (int q = 0; q < nvals; ++q) {
+    const double s = wave_sum(vals[q]);
+    if (lane == 0) red[wave * LRED + q] = s;
+  }
+  __syncthreads();
+  for (int q = 0; q < nvals; ++q) {
+    double t = 0.;
+#pragma unroll
+    for (int w = 0; w < LW; ++w) t += red[w * LRED + q];
+    vals[q] = t;
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ double wg_max(double x, double* red, int lane, int wave) {
+  x = wave_max(x);
+  if (lane == 0) red[wave * LRED] = x;
+  __syncthreads();
+  double t = red[0];
+#pragma unroll
+  for (int w = 1; w < LW; ++w) t = fmax(t, red[w * LRED]);
+  __syncthreads();
+  return t;
+}
+__device__ __forceinline__ bool wg_any(bool x, double* red, int lane, int wave) {
+  return __syncthreads_or(x ? 1 : 0) != 0;
+}
+
+template <int ND, bool ISO>
+__global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double* __restrict__ ws_base,
+                                                          const long long* __restrict__ ws_off) {
+  constexpr int NP = 2 + ND + (ISO ? 1 : ND);
+  constexpr int NSZ = ISO ? 1 : ND;
+  constexpr int MAXPF = 7;   // per-feature variables: signal + ND positions + NSZ sizes
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cl = k.order[blockIdx.x];
+  const int f0 = k.feat_offset[cl], n = k.feat_offset[cl + 1] - f0;
+  const double* params = k.params + (size_t)f0 * NP;
+  double* pout = k.params_out + (size_t)f0 * NP;
+  double* red = smem + SmemL::o_red;
+  double* tot = smem + SmemL::o_tot;
+  double* shs = smem + SmemL::o_sh;       // [0..63] factor of the shared block, [64..] vectors
+  double* myrows = smem + SmemL::o_rows + wave * (WAVE * LRS);
+
+  LayoutB L;
+  make_layout_b(k.prob, n, L);
+  const int nv = L.nv, NS = L.nshared, NPF = L.npf;
+  // columns of the 16-wide row: residual, shared, own, and the "owned pixel" copies
+  const int c_own = 1 + NS, c_reso = 1 + NS + NPF, c_sho = 2 + NS + NPF;
+  const LargeWs W = large_ws(n, NPF, NS);
+  double* ws = ws_base + ws_off[cl];
+  double *v = ws + W.o_vec, *vt = v + W.nvp, *v0 = vt + W.nvp, *lo = v0 + W.nvp, *hi = lo + W.nvp,
+         *g = hi + W.nvp, *xs = g + W.nvp, *rs = xs + W.nvp, *zs = rs + W.nvp, *ps = zs + W.nvp,
+         *Aps = ps + W.nvp, *dl = Aps + W.nvp, *Dm = dl + W.nvp, *fre = Dm + W.nvp;
+  double *cur = ws + W.o_cur, *mco = ws + W.o_mco, *fpar = ws + W.o_fpar, *pre = ws + W.o_pre,
+         *uq = ws + W.o_uq;
+  double* tileA = ws + W.o_tile;                 // accepted point
+  double* tileB = tileA + (size_t)n * 256;       // trial point
+  double* offA = ws + W.o_off;
+  double* offB = offA + (size_t)n * LARGE_MAXNB * 64;
+  int* nbcnt = (int*)(ws + W.o_int);
+  int* nbidx = nbcnt + W.nvp_i;
+  int* rev = nbidx + (size_t)n * LARGE_MAXNB;
+
+  // the exact second-order terms need signal and positions as per-feature variables
+  bool newton_on = L.slot[1] >= 0 && L.per_feat[1];
+#pragma unroll
+  for (int a = 0; a < ND; ++a) newton_on = newton_on && L.slot[2 + a] >= 0 && L.per_feat[2 + a];
+  // kind of per-feature slot s: 0 signal, 1 + a position axis a, -1 anything else
+  int kind_of[MAXPF];
+#pragma unroll
+  for (int s2 = 0; s2 < MAXPF; ++s2) {
+    int kd = -1;
+    if (L.per_feat[1] && L.slot[1] == s2) kd = 0;
+#pragma unroll
+    for (int a = 0; a < ND; ++a)
+      if (L.per_feat[2 + a] && L.slot[2 + a] == s2) kd = 1 + a;
+    kind_of[s2] = kd;
+  }
+  bool size_is_var = false;
+#pragma unroll
+  for (int kk = 2 + ND; kk < NP; ++kk) size_is_var = size_is_var || L.slot[kk] >= 0;
+
+  const void* frame = (const char*)k.frames + (size_t)k.frame_index[cl] * k.frame_elems * dtype_size(k.frame_dtype);
+  const int maxiter = k.prob.solver_maxiter > 0 ? k.prob.solver_maxiter : 100;
+  const double xtol = k.prob.xtol > 0 ? k.prob.xtol : 1e-9;
+  const double ftol = k.prob.ftol > 0 ? k.prob.ftol : 1e-14;
+  int radius[ND];
+  double inv_r2[ND];
+  long fshape[ND];
+#pragma unroll
+  for (int a = 0; a < ND; ++a) {
+    radius[a] = k.prob.radius[a];
+    inv_r2[a] = 1. / ((double)radius[a] * (double)radius[a]);
+    fshape[a] = k.shape[a];
+  }
+  auto par = [&](const double* vv, int i, int kk) -> double {
+    const int b = L.vidx(kk, i);
+    if (b < 0) return cur[i * CTR_MAX_PARAMS + kk];
+    return vv[b];
+  };
+
+  // ---- set-up ------------------------------------------------------------------------------
+  bool finite = true;
+  for (int e = tid; e < n * NP; e += LT) {
+    const double x = params[e];
+    pout[e] = x;  // failures keep their input (refine.py:408-418)
+    cur[(e / NP) * CTR_MAX_PARAMS + (e % NP)] = x;
+    if (!isfinite(x)) finite = false;
+  }
+  for (int e = tid; e < LW * WAVE * LRS; e += LT) smem[SmemL::o_rows + e] = 0.;
+  for (int e = tid; e < n * 3; e += LT) {
+    const int i = e / 3, a = e % 3;
+    mco[e] = a < ND ? params[i * NP + 2 + a] : 0.;
+  }
+  if (k.params_std != nullptr)   // (no covariance output for clusters of this size: documented)
+    for (int e = tid; e < n * NP; e += LT) k.params_std[(size_t)f0 * NP + e] = NAN;
+  {
+    const double* low = k.low + (size_t)f0 * NP;
+    const double* high = k.high + (size_t)f0 * NP;
+#pragma unroll
+    for (int kk = 0; kk < NP; ++kk) {
+      if (L.slot[kk] < 0) continue;
+      if (L.per_feat[kk]) {
+        for (int i = tid; i < n; i += LT) {
+          const int b = L.vidx(kk, i);
+          v0[b] = params[i * NP + kk];
+          lo[b] = low[i * NP + kk];
+          hi[b] = high[i * NP + kk];
+        }
+      } else {
+        // shared: mean start (refine.py:361), loosest bound (fitfunc.py:554-557)
+        double s = 0., l = INFINITY, h = -INFINITY;
+        for (int i = tid; i < n; i += LT) {
+          s += params[i * NP + kk];
+          l = fmin(l, low[i * NP + kk]);
+          h = fmax(h, high[i * NP + kk]);
+        }
+        double sv[1] = {s};
+        wg_sum(sv, 1, red, lane, wave);
+        l = -wg_max(-l, red, lane, wave);
+        h = wg_max(h, red, lane, wave);
+        if (tid == 0) {
+          const int b = L.vidx(kk, 0);
+          v0[b] = sv[0] / n;
+          lo[b] = l;
+          hi[b] = h;
+        }
+      }
+    }
+  }
+  const bool nonfinite = wg_any(!finite, red, lane, wave);
+
+  int status = nonfinite ? CTR_STATUS_NONFINITE : (n <= 0 ? CTR_STATUS_OUT_OF_BOUNDS : CTR_STATUS_OK);
+  int round = 0, it = 0, iters = 0, Pround = 0;
+  double mu = 1e-3, nu = 2., S = 0., pred = 0., rms = NAN, gain = INFINITY;
+  bool last_acc = true, bad_size = false;
+  const double fm = k.fmax[k.frame_index[cl]];
+  const double norm = fm * fm / k.prob.residual_factor;  // refine.py:354
+  const double ms2 = k.prob.max_shift * k.prob.max_shift;
+  int origin[ND], wshape[ND];
+#pragma unroll
+  for (int a = 0; a < ND; ++a) { origin[a] = 0; wshape[a] = 1; }
+
+  // derived constants of every feature at vv: [0] signal [1..3] centre [4..6] 1/size^2
+  // [7..9] 2/size^2 [10..12] -2/size^3
+  auto fill_fpar = [&](const double* vv, bool sizes) {
+    bool bad = false;
+    for (int i = tid; i < n; i += LT) {
+      double* f = fpar + (size_t)i * FP;
+      f[0] = par(vv, i, 1);
+#pragma unroll
+      for (int a = 0; a < ND; ++a) {
+        f[1 + a] = par(vv, i, 2 + a);
+        if (sizes) {
+          const double sz = par(vv, i, ISO ? 2 + ND : 2 + ND + a);
+          const double s2 = sz * sz;
+          bad = bad || !(sz > 0.);
+          f[4 + a] = 1. / s2;
+          f[7 + a] = 2. / s2;
+          f[10 + a] = -2. / (s2 * sz);
+        }
+      }
+    }
+    if (sizes) bad_size = wg_any(bad, red, lane, wave);
+    else __syncthreads();
+  };
+
+  // One pass over the masks at the point whose derived constants are in fpar: tiles and
+  // neighbour blocks -> (tile, off); returns P (union pixels) -- all threads.  bgv: background.
+  auto evaluate = [&](double* tile, double* off, double bgv, int& Pout) {
+    int Pown = 0;
+    const bool bg_var = L.slot[0] >= 0;
+    for (int i = wave; i < n; i += LW) {
+      // box of mask i inside the window (window indices)
+      int blo[ND], bsz[ND];
+      double rel_i[ND];
+      int npx = 1;
+#pragma unroll
+      for (int a = 0; a < ND; ++a) {
+        rel_i[a] = mco[i * 3 + a] - (double)origin[a];
+        int l = (int)ceil(rel_i[a] - (double)radius[a]), u = (int)floor(rel_i[a] + (double)radius[a]);
+        l = l < 0 ? 0 : l;
+        u = u > wshape[a] - 1 ? wshape[a] - 1 : u;
+        blo[a] = l;
+        bsz[a] = u >= l ? u - l + 1 : 0;
+        npx *= bsz[a];
+      }
+      const int cnt = nbcnt[i];
+      const int* nb = nbidx + (size_t)i * LARGE_MAXNB;
+      const double* fi = fpar + (size_t)i * FP;
+      v4d acc = v4d{0., 0., 0., 0.};
+      constexpr int NUF = ND * (ND + 1) / 2;
+      double uacc[NUF];
+#pragma unroll
+      for (int t = 0; t < NUF; ++t) uacc[t] = 0.;
+      double* row = myrows + lane * LRS;
+      for (int base = 0; base < npx; base += WAVE) {
+        const int q = base + lane;
+        int idx[ND];
+        bool in_i = false;
+        size_t offp = 0;
+        if (q < npx) {
+          int t = q;
+#pragma unroll
+          for (int a = ND - 1; a >= 0; --a) {
+            const int w = bsz[a];
+            const int c2 = t % w;
+            t /= w;
+            idx[a] = blo[a] + c2;
+          }
+          in_i = in_mask<ND>(idx, rel_i, inv_r2, radius);
+          if (ND == 3)
+            offp = ((size_t)(idx[0] + origin[0]) * fshape[1] + (idx[1] + origin[1])) * fshape[ND - 1] + (idx[ND - 1] + origin[ND - 1]);
+          else
+            offp = (size_t)(idx[0] + origin[0]) * fshape[ND - 1] + (idx[ND - 1] + origin[ND - 1]);
+        } else {
+#pragma unroll
+          for (int a = 0; a < ND; ++a) idx[a] = 0;
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < 16; ++c2) row[c2] = 0.;
+        if (in_i) {
+          const double pix = load_pixel(frame, k.frame_dtype, offp);
+          double res = pix - bgv;
+          bool owner = true;
+          double shared[CTR_MAX_PARAMS], down[1 + ND + NSZ];
+#pragma unroll
+          for (int kk = 0; kk < CTR_MAX_PARAMS; ++kk) shared[kk] = 0.;
+#pragma unroll
+          for (int t = 0; t < 1 + ND + NSZ; ++t) down[t] = 0.;
+          double Eown[ND];
+#pragma unroll
+          for (int a = 0; a < ND; ++a) Eown[a] = 0.;
+          // the features that cover this pixel: i itself and its neighbours (ascending order)
+          for (int s2 = -1; s2 < cnt; ++s2) {
+            const int j = s2 < 0 ? i : nb[s2];
+            const double* f = s2 < 0 ? fi : fpar + (size_t)j * FP;
+            if (s2 >= 0) {
+              double rel[ND];
+#pragma unroll
+              for (int a = 0; a < ND; ++a) rel[a] = mco[j * 3 + a] - (double)origin[a];
+              if (!in_mask<ND>(idx, rel, inv_r2, radius)) continue;
+              if (j < i) owner = false;
+            }
+            double r2 = 0., dd[ND], d[1 + ND + NSZ];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              dd[a] = (double)(idx[a] + origin[a]) - f[1 + a];
+              r2 += dd[a] * dd[a] * f[4 + a];
+            }
+            const double gv = exp(-0.5 * ND * r2);  // fitfunc.py:112-118
+            const double sig = f[0];
+            const double sdg = sig * (0.5 * ND) * gv;
+            res -= sig * gv;
+            d[0] = -gv;
+            double q2 = 0.;
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              d[1 + a] = sdg * (-dd[a] * f[7 + a]);
+              if (ISO) q2 += dd[a] * dd[a];
+              else d[1 + ND + a] = sdg * (dd[a] * dd[a] * f[10 + a]);
+            }
+            if (ISO) d[1 + ND] = sdg * (q2 * f[10]);
+#pragma unroll
+            for (int kk = 1; kk < NP; ++kk) shared[kk] += d[kk - 1];
+            if (s2 < 0) {
+#pragma unroll
+              for (int t = 0; t < 1 + ND + NSZ; ++t) down[t] = d[t];
+#pragma unroll
+              for (int a = 0; a < ND; ++a) Eown[a] = (double)ND * (dd[a] * f[4 + a]);
+            }
+          }
+          Pown += owner ? 1 : 0;
+          if (res == res) {   // nansum (fitfunc.py:449,483): a NaN pixel counts in P only
+            const double ow = owner ? 1. : 0.;
+            row[0] = res;
+            row[c_reso] = ow * res;
+            if (bg_var) { row[1 + L.slot[0]] = -1.; row[c_sho + L.slot[0]] = -ow; }
+#pragma unroll
+            for (int kk = 1; kk < NP; ++kk) {
+              if (L.slot[kk] < 0) continue;
+              if (L.per_feat[kk]) row[c_own + L.slot[kk]] = down[kk - 1];
+              else { row[1 + L.slot[kk]] = shared[kk]; row[c_sho + L.slot[kk]] = ow * shared[kk]; }
+            }
+            if (newton_on) {
+              int e = 0;
+#pragma unroll
+              for (int a = 0; a < ND; ++a) {
+                const double rj = res * down[1 + a];
+#pragma unroll
+                for (int b2 = a; b2 < ND; ++b2) { uacc[e] += rj * Eown[b2]; ++e; }
+              }
+            }
+          }
+        }
+        wsync();
+        {
+          const double* rbase = myrows + (lane >> 4) * LRS + (lane & 15);
+#pragma unroll 4
+          for (int s2 = 0; s2 < 16; ++s2) {
+            const double x = rbase[4 * s2 * LRS];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+          }
+        }
+        wsync();
+      }
+      // D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+      {
+        double* t = tile + (size_t)i * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
+      }
+      if (newton_on) {
+#pragma unroll
+        for (int t = 0; t < NUF; ++t) {
+          const double s = wave_sum(uacc[t]);
+          if (lane == 0) uq[(size_t)i * 16 + LQT + t] = s;   // raw sums of the TRIAL point (tabulated on accept)
+        }
+      }
+      // ---- neighbour blocks: d_i d_j^T over mask i & mask j, for the neighbours j > i -------
+      for (int s2 = 0; s2 < cnt; ++s2) {
+        const int j = nb[s2];
+        if (j < i) continue;
+        const double* fj = fpar + (size_t)j * FP;
+        double rel_j[ND];
+        int plo[ND], psz[ND], np2 = 1;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+          rel_j[a] = mco[j * 3 + a] - (double)origin[a];
+          int l = (int)ceil(rel_j[a] - (double)radius[a]), u = (int)floor(rel_j[a] + (double)radius[a]);
+          l = l < blo[a] ? blo[a] : l;
+          u = u > blo[a] + bsz[a] - 1 ? blo[a] + bsz[a] - 1 : u;
+          plo[a] = l;
+          psz[a] = u >= l ? u - l + 1 : 0;
+          np2 *= psz[a];
+        }
+        acc = v4d{0., 0., 0., 0.};
+        for (int base = 0; base < np2; base += WAVE) {
+          const int q = base + lane;
+          bool both = false;
+          int idx[ND];
+          size_t offp = 0;
+          if (q < np2) {
+            int t = q;
+#pragma unroll
+            for (int a = ND - 1; a >= 0; --a) {
+              const int w = psz[a];
+              const int c2 = t % w;
+              t /= w;
+              idx[a] = plo[a] + c2;
+            }
+            both = in_mask<ND>(idx, rel_i, inv_r2, radius) && in_mask<ND>(idx, rel_j, inv_r2, radius);
+            if (ND == 3)
+              offp = ((size_t)(idx[0] + origin[0]) * fshape[1] + (idx[1] + origin[1])) * fshape[ND - 1] + (idx[ND - 1] + origin[ND - 1]);
+            else
+              offp = (size_t)(idx[0] + origin[0]) * fshape[ND - 1] + (idx[ND - 1] + origin[ND - 1]);
+          } else {
+#pragma unroll
+            for (int a = 0; a < ND; ++a) idx[a] = 0;
+          }
+          if (__ballot(both) == 0ull) continue;
+#pragma unroll
+          for (int c2 = 0; c2 < 16; ++c2) row[c2] = 0.;
+          if (both) {
+            const double pix = load_pixel(frame, k.frame_dtype, offp);
+            if (pix == pix) {   // (a NaN pixel of the image contributes nothing)
+#pragma unroll
+              for (int side = 0; side < 2; ++side) {
+                const double* f = side == 0 ? fi : fj;
+                double r2 = 0., dd[ND], d[1 + ND + NSZ];
+#pragma unroll
+                for (int a = 0; a < ND; ++a) {
+                  dd[a] = (double)(idx[a] + origin[a]) - f[1 + a];
+                  r2 += dd[a] * dd[a] * f[4 + a];
+                }
+                const double gv = exp(-0.5 * ND * r2);
+                const double sdg = f[0] * (0.5 * ND) * gv;
+                d[0] = -gv;
+                double q2 = 0.;
+#pragma unroll
+                for (int a = 0; a < ND; ++a) {
+                  d[1 + a] = sdg * (-dd[a] * f[7 + a]);
+                  if (ISO) q2 += dd[a] * dd[a];
+                  else d[1 + ND + a] = sdg * (dd[a] * dd[a] * f[10 + a]);
+                }
+                if (ISO) d[1 + ND] = sdg * (q2 * f[10]);
+#pragma unroll
+                for (int kk = 1; kk < NP; ++kk)
+                  if (L.slot[kk] >= 0 && L.per_feat[kk]) row[8 * side + L.slot[kk]] = d[kk - 1];
+              }
+            }
+          }
+          wsync();
+          {
+            const double* rbase = myrows + (lane >> 4) * LRS + (lane & 15);
+#pragma unroll 4
+            for (int s3 = 0; s3 < 16; ++s3) {
+              const double x = rbase[4 * s3 * LRS];
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+            }
+          }
+          wsync();
+        }
+        // rows 0..7 = d_i, columns 8..15 = d_j: block (a, b) at acc[row a][col 8 + b]; both directions
+        {
+          const int col = lane & 15;
+          double* oij = off + ((size_t)i * LARGE_MAXNB + s2) * 64;
+          double* oji = off + ((size_t)j * LARGE_MAXNB + rev[(size_t)i * LARGE_MAXNB + s2]) * 64;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rw = (lane >> 4) + 4 * r;
+            if (rw < 8 && col >= 8) {
+              oij[rw * 8 + (col - 8)] = acc[r];
+              oji[(col - 8) * 8 + rw] = acc[r];
+            }
+          }
+        }
+      }
+    }
+    // sums over the features of every tile entry: the "_o" entries are the cluster totals
+    __syncthreads();
+    if (tid < 256) {
+      double s = 0.;
+      for (int i = 0; i < n; ++i) s += tile[(size_t)i * 256 + tid];
+      tot[tid] = s;
+    }
+    double pv[1] = {(double)Pown};
+    wg_sum(pv, 1, red, lane, wave);   // (also orders tot[] for everybody)
+    Pout = (int)pv[0];
+  };
+
+  // y = (B + mu diag(Dm)) x on the variables with mk != nullptr ? mk == 1 : all; B = J^T J of
+  // (tile, off) plus, with use_q, the second-order entries uq.  Returns x^T y (all threads).
+  auto matvec = [&](const double* x, double* y, const double* tile, const double* off, double muv,
+                    bool use_q, const double* mk) -> double {
+    __syncthreads();
+    double part[1 + 8];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) part[q] = 0.;
+    double xsh[8];
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) xsh[kq] = kq < NS ? x[kq] * (mk ? mk[kq] : 1.) : 0.;
+    for (int i = tid; i < n; i += LT) {
+      const int b0 = NS + i * NPF;
+      const double* t = tile + (size_t)i * 256;
+      double xi[MAXPF], yi[MAXPF];
+#pragma unroll
+      for (int a = 0; a < MAXPF; ++a) { xi[a] = a < NPF ? x[b0 + a] * (mk ? mk[b0 + a] : 1.) : 0.; yi[a] = 0.; }
+#pragma unroll
+      for (int a = 0; a < MAXPF; ++a) {
+        if (a >= NPF) continue;
+        double s = muv * Dm[b0 + a] * xi[a];
+#pragma unroll
+        for (int b = 0; b < MAXPF; ++b)
+          if (b < NPF) s += t[(c_own + a) * 16 + c_own + b] * xi[b];
+#pragma unroll
+        for (int kq = 0; kq < 8; ++kq)
+          if (kq < NS) s += t[(c_own + a) * 16 + 1 + kq] * xsh[kq];
+        yi[a] = s;
+      }
+      if (use_q) {
+        // second-order part between (signal, positions) of this feature
+        const double* u = uq + (size_t)i * 16;
+#pragma unroll
+        for (int a = 0; a < MAXPF; ++a)
+#pragma unroll
+          for (int b = 0; b < MAXPF; ++b) {
+            if (a >= NPF || b >= NPF) continue;
+            const int ka = kind_of[a], kb = kind_of[b];
+            if (ka < 0 || kb < 0 || ka + kb == 0) continue;
+            const int k0 = ka < kb ? ka : kb, k1 = ka < kb ? kb : ka;
+            const int e = k0 == 0 ? k1 - 1 : ND + ((k0 - 1) * ND - ((k0 - 1) * (k0 - 2)) / 2 + (k1 - k0));
+            yi[a] += u[e] * xi[b];
+          }
+      }
+      const int cnt = nbcnt[i];
+      for (int s2 = 0; s2 < cnt; ++s2) {
+        const int j = nbidx[(size_t)i * LARGE_MAXNB + s2];
+        const double* o = off + ((size_t)i * LARGE_MAXNB + s2) * 64;
+        const int bj = NS + j * NPF;
+#pragma unroll
+        for (int b = 0; b < MAXPF; ++b) {
+          if (b >= NPF) continue;
+          const double xj = x[bj + b] * (mk ? mk[bj + b] : 1.);
+#pragma unroll
+          for (int a = 0; a < MAXPF; ++a)
+            if (a < NPF) yi[a] += o[a * 8 + b] * xj;
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < MAXPF; ++a) {
+        if (a >= NPF) continue;
+        const double ya = yi[a] * (mk ? mk[b0 + a] : 1.);
+        y[b0 + a] = ya;
+        part[0] += xi[a] * ya;
+#pragma unroll
+        for (int kq = 0; kq < 8; ++kq)
+          if (kq < NS) part[1 + kq] += t[(c_own + a) * 16 + 1 + kq] * xi[a];
+      }
+    }
+    wg_sum(part, 1 + NS, red, lane, wave);
+    double dot = part[0];
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) {
+      if (kq >= NS) continue;
+      double s = part[1 + kq] + muv * Dm[kq] * xsh[kq];
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2)
+        if (k2 < NS) s += tot[(c_sho + kq) * 16 + c_sho + k2] * xsh[k2];
+      s *= mk ? mk[kq] : 1.;
+      if (tid == 0) y[kq] = s;
+      dot += xsh[kq] * s;
+    }
+    __syncthreads();
+    return dot;
+  };
+
+  // ---- rounds ----------------------------------------------------------------------------------
+  bool tiles_swapped = false;   // accepted data in tileB/offB
+  while (status == CTR_STATUS_OK) {
+    // window of this round (masks.py:42-68) from the mask centres
+    {
+      double mn[ND], mx[ND];
+      bool any = false;
+#pragma unroll
+      for (int a = 0; a < ND; ++a) { mn[a] = INFINITY; mx[a] = -INFINITY; }
+      for (int i = tid; i < n; i += LT) {
+        double ci[ND];
+        bool ok = true;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+          ci[a] = rint(mco[i * 3 + a]);
+          if (!(ci[a] >= -(double)radius[a] && ci[a] < (double)fshape[a] + radius[a])) ok = false;
+        }
+        if (ok) {
+          any = true;
+#pragma unroll
+          for (int a = 0; a < ND; ++a) { mn[a] = fmin(mn[a], ci[a]); mx[a] = fmax(mx[a], ci[a]); }
+        }
+      }
+      if (!wg_any(any, red, lane, wave)) { status = CTR_STATUS_OUT_OF_BOUNDS; break; }
+#pragma unroll
+      for (int a = 0; a < ND; ++a) {
+        const double l0 = -wg_max(-mn[a], red, lane, wave), u0 = wg_max(mx[a], red, lane, wave);
+        long l = (long)l0 - radius[a], u = (long)u0 + radius[a] + 1;
+        l = l < 0 ? 0 : l;
+        u = u > fshape[a] ? fshape[a] : u;
+        origin[a] = (int)l;
+        wshape[a] = (int)(u - l);
+      }
+    }
+    // neighbour lists: features whose mask boxes overlap (a superset of overlapping masks)
+    bool overflow = false;
+    for (int i = tid; i < n; i += LT) {
+      int cnt = 0;
+      for (int j = 0; j < n; ++j) {
+        if (j == i) continue;
+        bool near = true;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) near = near && fabs(mco[i * 3 + a] - mco[j * 3 + a]) <= 2. * radius[a] + 1e-9;
+        if (near) {
+          if (cnt < LARGE_MAXNB) nbidx[(size_t)i * LARGE_MAXNB + cnt] = j;
+          ++cnt;
+        }
+      }
+      if (cnt > LARGE_MAXNB) { overflow = true; cnt = LARGE_MAXNB; }
+      nbcnt[i] = cnt;
+    }
+    if (wg_any(overflow, red, lane, wave)) { status = CTR_STATUS_TOO_LARGE; break; }
+    for (int i = tid; i < n; i += LT) {
+      const int cnt = nbcnt[i];
+      for (int s2 = 0; s2 < cnt; ++s2) {
+        const int j = nbidx[(size_t)i * LARGE_MAXNB + s2];
+        int r = 0;
+        for (int s3 = 0; s3 < nbcnt[j]; ++s3)
+          if (nbidx[(size_t)j * LARGE_MAXNB + s3] == i) r = s3;
+        rev[(size_t)i * LARGE_MAXNB + s2] = r;
+      }
+    }
+    // trial = clipped start vector
+    bool infeasible = false;
+    for (int i = tid; i < nv; i += LT) {
+      if (lo[i] > hi[i]) infeasible = true;
+      const double x = v0[i];
+      vt[i] = x < lo[i] ? lo[i] : (x > hi[i] ? hi[i] : x);
+    }
+    if (wg_any(infeasible, red, lane, wave)) { status = CTR_STATUS_NO_CONVERGENCE; break; }
+    fill_fpar(vt, size_is_var || round == 0);
+    it = 0;
+    mu = 1e-3; nu = 2.; last_acc = true; gain = INFINITY;
+
+    // ---- one solver run ------------------------------------------------------------------
+    bool need_eval = true, first = true, converged = false, failed = false;
+    while (!converged && !failed) {
+      double* tileT = tiles_swapped ? tileA : tileB;   // where a trial evaluation goes
+      double* offT = tiles_swapped ? offA : offB;
+      bool accept = false;
+      if (need_eval) {
+        int P = 0;
+        evaluate(tileT, offT, par(vt, 0, 0), P);
+        double St = tot[c_reso * 16 + c_reso];
+        if (bad_size) St = NAN;
+        if (first) {
+          if (P == 0) { status = CTR_STATUS_OUT_OF_BOUNDS; failed = true; }
+          else if (!isfinite(St)) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+          Pround = P;
+          accept = !failed;
+          first = false;
+        } else {
+          const double act = 0.5 * (S - St);
+          if (isfinite(St) && pred > 0. && act > 0.) {
+            const double rho = act / pred, t = 2. * rho - 1.;
+            const double f = 1. - t * t * t;
+            mu *= f > 1. / 3. ? f : 1. / 3.;
+            nu = 2.;
+            gain = act / (0.5 * S + 1e-300);
+            accept = true;
+            last_acc = true;
+          } else {
+            mu *= nu; nu *= 2.; last_acc = false;
+            if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+          }
+        }
+        if (accept) {
+          S = St;
+          tiles_swapped = !tiles_swapped;   // the trial data are the accepted data now
+          const double* tl = tiles_swapped ? tileB : tileA;
+          for (int i = tid; i < nv; i += LT) v[i] = vt[i];
+          // gradient J^T r, Marquardt diagonal, second-order entries at the new point
+          if (tid < NS) {
+            g[tid] = tot[(c_sho + tid) * 16 + c_reso];
+            Dm[tid] = tot[(c_sho + tid) * 16 + c_sho + tid];
+          }
+          for (int i = tid; i < n; i += LT) {
+            const double* t = tl + (size_t)i * 256;
+            const int b0 = NS + i * NPF;
+            for (int a = 0; a < NPF; ++a) {
+              g[b0 + a] = t[(c_own + a) * 16];
+              Dm[b0 + a] = t[(c_own + a) * 16 + c_own + a];
+            }
+            if (newton_on) {
+              // block_kernel.h / oracle eval_cluster: d2res/ds dpos_a = g_pos_a / s,
+              // d2res/dpos_a dpos_b = U_ab + delta_ab (-ND/size_a^2) s g_s
+              double* u = uq + (size_t)i * 16;
+              const double sig = vt[b0 + L.slot[1]], gs = t[(c_own + L.slot[1]) * 16];
+              int e = 0;
+#pragma unroll
+              for (int a = 0; a < ND; ++a) {
+                const double ga = t[(c_own + L.slot[2 + a]) * 16];
+                u[a] = sig != 0. ? ga / sig : 0.;
+#pragma unroll
+                for (int b2 = a; b2 < ND; ++b2) {
+                  double q = u[LQT + e];
+                  if (b2 == a) {
+                    const double sz = par(vt, i, ISO ? 2 + ND : 2 + ND + a);
+                    q += -(double)ND / (sz * sz) * sig * gs;
+                  }
+                  u[ND + e] = q;
+                  ++e;
+                }
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+      need_eval = false;
+      if (failed) break;
+      if (it >= maxiter) {
+        // iteration limit: a stationary point still counts as converged (oracle solve())
+        if (gain <= CTR_STALL_TOL) { converged = true; break; }
+        status = CTR_STATUS_NO_CONVERGENCE; failed = true; break;
+      }
+      ++it;
+      ++iters;
+      const double* tl = tiles_swapped ? tileB : tileA;
+      const double* ol = tiles_swapped ? offB : offA;
+      // active set: fixed if at a bound and the gradient pushes outward
+      double nfv[1] = {0.};
+      for (int i = tid; i < nv; i += LT) {
+        const double gl = g[i];
+        const bool fixed = (lo[i] == hi[i]) || (v[i] <= lo[i] && gl > 0.) || (v[i] >= hi[i] && gl < 0.);
+        fre[i] = fixed ? 0. : 1.;
+        nfv[0] += fixed ? 0. : 1.;
+      }
+      wg_sum(nfv, 1, red, lane, wave);
+      if (nfv[0] == 0.) { converged = true; break; }
+      const double tiny = ftol * (0.5 * S) + 1e-300;
+      bool ok_step = false;
+      double stepmax = 0.;
+      for (int attempt = newton_on ? 1 : 0; attempt >= 0 && !ok_step; --attempt) {
+        const bool nwt = attempt == 1;
+        // ---- preconditioner: Cholesky factors of the diagonal blocks (fixed rows = identity)
+        bool notpd = false;
+        for (int i = tid; i < n; i += LT) {
+          const double* t = tl + (size_t)i * 256;
+          const double* u = uq + (size_t)i * 16;
+          const int b0 = NS + i * NPF;
+          double Lm[MAXPF][MAXPF];
+#pragma unroll
+          for (int a = 0; a < MAXPF; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) {
+              double h = 0.;
+              if (a < NPF) {
+                const bool fa = fre[b0 + a] != 0., fb = fre[b0 + b] != 0.;
+                if (fa && fb) {
+                  h = t[(c_own + a) * 16 + c_own + b];
+                  if (nwt) {
+                    const int ka = kind_of[a], kb = kind_of[b];
+                    if (ka >= 0 && kb >= 0 && ka + kb > 0) {
+                      const int k0 = ka < kb ? ka : kb, k1 = ka < kb ? kb : ka;
+                      h += u[k0 == 0 ? k1 - 1 : ND + ((k0 - 1) * ND - ((k0 - 1) * (k0 - 2)) / 2 + (k1 - k0))];
+                    }
+                  }
+                  if (a == b) h += mu * Dm[b0 + a];
+                } else if (a == b) h = 1.;
+              } else if (a == b) h = 1.;
+              Lm[a][b] = h;
+            }
+          bool okc = true;
+#pragma unroll
+          for (int j = 0; j < MAXPF; ++j) {
+            double d = Lm[j][j];
+#pragma unroll
+            for (int q = 0; q < j; ++q) d -= Lm[j][q] * Lm[j][q];
+            if (!(d > 0.) || !isfinite(d)) okc = false;
+            const double di = 1. / sqrt(d);
+            Lm[j][j] = di;   // (the reciprocal of the pivot)
+#pragma unroll
+            for (int r = j + 1; r < MAXPF; ++r) {
+              double s = Lm[r][j];
+#pragma unroll
+              for (int q = 0; q < j; ++q) s -= Lm[r][q] * Lm[j][q];
+              Lm[r][j] = s * di;
+            }
+          }
+          if (!okc) notpd = true;
+          double* pf = pre + (size_t)i * 32;
+          int e = 0;
+#pragma unroll
+          for (int a = 0; a < MAXPF; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) pf[e++] = Lm[a][b];
+        }
+        // shared block (NS <= 6): thread 0, in LDS
+        if (tid == 0) {
+          bool okc = true;
+          for (int a = 0; a < NS; ++a)
+            for (int b = 0; b <= a; ++b) {
+              double h;
+              if (fre[a] != 0. && fre[b] != 0.) {
+                h = tot[(c_sho + a) * 16 + c_sho + b];
+                if (a == b) h += mu * Dm[a];
+              } else h = a == b ? 1. : 0.;
+              shs[a * 8 + b] = h;
+            }
+          for (int j = 0; j < NS; ++j) {
+            double d = shs[j * 8 + j];
+            for (int q = 0; q < j; ++q) d -= shs[j * 8 + q] * shs[j * 8 + q];
+            if (!(d > 0.) || !isfinite(d)) okc = false;
+            const double di = 1. / sqrt(d);
+            shs[j * 8 + j] = di;
+            for (int r = j + 1; r < NS; ++r) {
+              double s = shs[r * 8 + j];
+              for (int q = 0; q < j; ++q) s -= shs[r * 8 + q] * shs[j * 8 + q];
+              shs[r * 8 + j] = s * di;
+            }
+          }
+          if (!okc) notpd = true;
+        }
+        if (wg_any(notpd, red, lane, wave)) continue;
+        // z = P^-1 r on this thread's features (and, thread 0, the shared block); returns r.z
+        auto precond = [&](const double* rr, double* zz) -> double {
+          double acc2 = 0.;
+          for (int i = tid; i < n; i += LT) {
+            const double* pf = pre + (size_t)i * 32;
+            const int b0 = NS + i * NPF;
+            double y[MAXPF];
+#pragma unroll
+            for (int a = 0; a < MAXPF; ++a) {
+              double s = a < NPF ? rr[b0 + a] : 0.;
+#pragma unroll
+              for (int q = 0; q < a; ++q) s -= pf[a * (a + 1) / 2 + q] * y[q];
+              y[a] = s * pf[a * (a + 1) / 2 + a];
+            }
+#pragma unroll
+            for (int a = MAXPF - 1; a >= 0; --a) {
+              double s = y[a];
+#pragma unroll
+              for (int q = a + 1; q < MAXPF; ++q) s -= pf[q * (q + 1) / 2 + a] * y[q];
+              y[a] = s * pf[a * (a + 1) / 2 + a];
+            }
+#pragma unroll
+            for (int a = 0; a < MAXPF; ++a)
+              if (a < NPF) { zz[b0 + a] = y[a]; acc2 += rr[b0 + a] * y[a]; }
+          }
+          if (tid == 0) {
+            double y[8];
+            for (int a = 0; a < NS; ++a) {
+              double s = rr[a];
+              for (int q = 0; q < a; ++q) s -= shs[a * 8 + q] * y[q];
+              y[a] = s * shs[a * 8 + a];
+            }
+            for (int a = NS - 1; a >= 0; --a) {
+              double s = y[a];
+              for (int q = a + 1; q < NS; ++q) s -= shs[q * 8 + a] * y[q];
+              y[a] = s * shs[a * 8 + a];
+            }
+            for (int a = 0; a < NS; ++a) { zz[a] = y[a]; acc2 += rr[a] * y[a]; }
+          }
+          return acc2;
+        };
+        // ---- conjugate gradients on the free variables: (B + mu D) x = g ----------------------
+        for (int i = tid; i < nv; i += LT) { xs[i] = 0.; rs[i] = g[i] * fre[i]; }
+        // (a thread touches the entries of "its" features in every phase; the shared entries are
+        //  thread 0's -- so only the matrix products and the sums need the barriers)
+        __syncthreads();
+        double rz[1] = {precond(rs, zs)};
+        wg_sum(rz, 1, red, lane, wave);
+        for (int i = tid; i < nv; i += LT) ps[i] = zs[i];
+        const double rz0 = rz[0];
+        bool cg_fail = !(rz0 >= 0.) || !isfinite(rz0);
+        const int cg_max = nv + 50;
+        for (int ci = 0; ci < cg_max && !cg_fail && rz[0] > 1e-26 * rz0 && rz[0] > 0.; ++ci) {
+          const double pAp = matvec(ps, Aps, tl, ol, mu, nwt, fre);
+          if (!(pAp > 0.) || !isfinite(pAp)) { cg_fail = true; break; }   // not positive definite
+          const double alpha = rz[0] / pAp;
+          for (int i = tid; i < n; i += LT)
+            for (int a = 0; a < NPF; ++a) {
+              const int e = NS + i * NPF + a;
+              xs[e] += alpha * ps[e];
+              rs[e] -= alpha * Aps[e];
+            }
+          if (tid == 0)
+            for (int a = 0; a < NS; ++a) { xs[a] += alpha * ps[a]; rs[a] -= alpha * Aps[a]; }
+          double rzn[1] = {precond(rs, zs)};
+          wg_sum(rzn, 1, red, lane, wave);
+          const double beta = rzn[0] / rz[0];
+          rz[0] = rzn[0];
+          for (int i = tid; i < n; i += LT)
+            for (int a = 0; a < NPF; ++a) {
+              const int e = NS + i * NPF + a;
+              ps[e] = zs[e] + beta * ps[e];
+            }
+          if (tid == 0)
+            for (int a = 0; a < NS; ++a) ps[a] = zs[a] + beta * ps[a];
+        }
+        if (cg_fail) continue;
+        __syncthreads();
+        // projected trial point
+        double sm = 0.;
+        for (int i = tid; i < nv; i += LT) {
+          double t = v[i] - xs[i] * fre[i];
+          t = t < lo[i] ? lo[i] : (t > hi[i] ? hi[i] : t);
+          vt[i] = t;
+          const double d = t - v[i];
+          dl[i] = d;
+          sm = fmax(sm, fabs(d) / (fabs(v[i]) + 1.));
+        }
+        stepmax = wg_max(sm, red, lane, wave);
+        // predicted decrease of the model along the actual step: -(g.dl + 1/2 dl^T B dl)
+        const double dBd = matvec(dl, Aps, tl, ol, 0., nwt, nullptr);
+        double gd[1] = {0.};
+        for (int i = tid; i < nv; i += LT) gd[0] += g[i] * dl[i];
+        wg_sum(gd, 1, red, lane, wave);
+        pred = -(gd[0] + 0.5 * dBd);
+        if (nwt && !(pred > -tiny)) continue;
+        ok_step = true;
+      }
+      if (!ok_step) {
+        mu *= nu; nu *= 2.; last_acc = false;
+        if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+        continue;
+      }
+      if ((last_acc && stepmax <= xtol) || fabs(pred) <= tiny) { converged = true; break; }
+      if (!(pred > 0.)) {
+        // the model itself predicts no decrease: rejected without a pixel pass
+        mu *= nu; nu *= 2.; last_acc = false;
+        if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
+        continue;
+      }
+      fill_fpar(vt, size_is_var);
+      need_eval = true;
+    }
+    if (failed || status != CTR_STATUS_OK) break;
+    // ---- end of a round: vect_to_params and the shift test (refine.py:379-388) ---------------
+    rms = sqrt(((S / (double)Pround) / norm) / k.prob.residual_factor);
+    bool moved = false;
+    for (int i = tid; i < n; i += LT) {
+      double d2 = 0.;
+#pragma unroll
+      for (int kk = 0; kk < NP; ++kk) {
+        const int b = L.vidx(kk, i);
+        if (b >= 0) cur[i * CTR_MAX_PARAMS + kk] = v[b];
+      }
+#pragma unroll
+      for (int a = 0; a < ND; ++a) {
+        const double d = cur[i * CTR_MAX_PARAMS + 2 + a] - mco[i * 3 + a];
+        d2 += d * d;
+      }
+      if (!(d2 < ms2)) moved = true;
+    }
+    const bool any_moved = wg_any(moved, red, lane, wave);
+    ++round;
+    if (!any_moved || round >= k.prob.max_iter) {
+      if (rms > k.prob.max_rms_dev) status = CTR_STATUS_RMS_DEV;  // refine.py:391
+      break;
+    }
+    for (int e = tid; e < n * 3; e += LT) {
+      const int i = e / 3, a = e % 3;
+      if (a < ND) mco[e] = cur[i * CTR_MAX_PARAMS + 2 + a];
+    }
+    __syncthreads();
+  }
+
+  __syncthreads();
+  const bool ok = status == CTR_STATUS_OK;
+  if (ok)
+    for (int e = tid; e < n * NP; e += LT) pout[e] = cur[(e / NP) * CTR_MAX_PARAMS + (e % NP)];
+  if (tid == 0) {
+    k.status[cl] = status;
+    k.cost[cl] = ok ? rms : NAN;
+    k.n_rounds[cl] = status == CTR_STATUS_NONFINITE || n <= 0 ? 0
+                   : (ok || status == CTR_STATUS_RMS_DEV ? round : round + 1);
+    k.n_iter[cl] = iters;
+  }
+}
+
+#endif  // CTREFINE_LARGE_KERNEL_H

@@ -248,8 +248,8 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
   const int64_t* fshape = c->b->shape;
   const int dtype = c->b->frame_dtype;
   double prm[CTR_MAX_PARAMS];
-  double row[MAXV];
-  int nz[MAXV];
+  double* row = malloc(sizeof(double) * (size_t)(nv > 0 ? nv : 1));
+  int* nz = malloc(sizeof(int) * (size_t)(nv > 0 ? nv : 1));
   double S = 0.;
   long P = 0;
   int model_nan = 0;
@@ -260,9 +260,17 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
   if (A) memset(A, 0, sizeof(double) * nv * nv);
   if (Q) memset(Q, 0, sizeof(double) * nv * nv);
   /* second-order part (see solve()): U[i][a][b] = sum_p res * J_pos_a * dE/dpos_b of feature i */
-  double U[MAXV][3][3];
-  struct { int i; double J[3], E[3]; } hf[MAXV];
-  if (Q) memset(U, 0, sizeof(double) * (size_t)n * 9);
+  double (*U)[3][3] = calloc((size_t)n, sizeof(double) * 9);
+  struct hf_t { int i; double J[3], E[3]; }* hf = malloc(sizeof(struct hf_t) * (size_t)n);
+  /* per feature: a box (window indices) that contains its mask -- features whose box misses
+   * the pixel are skipped without the ellipse test (large clusters); results unchanged */
+  int (*box)[2][3] = malloc(sizeof(int) * 6 * (size_t)n);
+  for (int i = 0; i < n; ++i)
+    for (int a = 0; a < nd; ++a) {
+      double rel = c->mcoords[i * nd + a] - (double)c->origin[a];
+      box[i][0][a] = (int)floor(rel - c->p->radius[a]) - 1;
+      box[i][1][a] = (int)ceil(rel + c->p->radius[a]) + 1;
+    }
   for (int z = 0; z < w0; ++z)
     for (int y = 0; y < w1; ++y)
       for (int x = 0; x < w2; ++x) {
@@ -280,6 +288,9 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
         }
         for (int a = 0; a < nd; ++a) mesh[a] = (double)(idx[a] + c->origin[a]);
         for (int i = 0; i < n; ++i) {
+          int inbox = 1;
+          for (int a = 0; a < nd; ++a) inbox = inbox && idx[a] >= box[i][0][a] && idx[a] <= box[i][1][a];
+          if (!inbox) continue;
           if (!in_mask(nd, idx, c->mcoords + i * nd, c->origin, c->p->radius)) continue;
           if (!any) {
             any = 1;
@@ -381,6 +392,7 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
   }
   *S_out = model_nan ? NAN : S;
   *P_out = P;
+  free(row); free(nz); free(U); free(hf); free(box);
 }
 
 /* ---- dense helpers -------------------------------------------------------- */
@@ -819,7 +831,7 @@ static void refine_one(const ctr_problem* p, const ctr_batch* b, int64_t cl,
   b->n_iter[cl] = 0;
   c.p = p; c.b = b;
   if (n <= 0) { b->status[cl] = CTR_STATUS_OUT_OF_BOUNDS; return; }
-  if (make_layout(p, n, &c.L) > MAXV) { b->status[cl] = CTR_STATUS_TOO_LARGE; return; }
+  make_layout(p, n, &c.L);   /* (the oracle has no size limit; constraints only for n <= 4) */
   for (int i = 0; i < n * np; ++i)
     if (!isfinite(params[i])) { b->status[cl] = CTR_STATUS_NONFINITE; return; } /* refine.py:356-357 */
   for (int a = 0; a < nd; ++a) felems *= (size_t)b->shape[a];
@@ -827,7 +839,8 @@ static void refine_one(const ctr_problem* p, const ctr_batch* b, int64_t cl,
   c.n_cons = n_constraints(p, n);
   {
     const int nv = c.L.nv;
-    double v0[MAXV], lo[MAXV], hi[MAXV], v[MAXV], vstd[MAXV];
+    double* vecs = malloc(sizeof(double) * 5 * (size_t)(nv > 0 ? nv : 1));
+    double *v0 = vecs, *lo = vecs + nv, *hi = vecs + 2 * nv, *v = vecs + 3 * nv, *vstd = vecs + 4 * nv;
     double* cur = malloc(sizeof(double) * (size_t)n * np);   /* params after the latest round */
     double* coords = malloc(sizeof(double) * (size_t)n * nd);
     const double fm = fmax[b->frame_index[cl]];
@@ -878,7 +891,7 @@ static void refine_one(const ctr_problem* p, const ctr_batch* b, int64_t cl,
             if (bb >= 0) b->params_std[(size_t)(f0 + i) * np + k] = vstd[bb + (c.L.per_feat[k] ? i : 0)];
           }
     }
-    (void)nv;
+    free(vecs);
     free(cur);
     free(coords);
   }

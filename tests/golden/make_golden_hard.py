@@ -75,9 +75,46 @@ def tetramer2d():
     mg.save_case('tetramer2d_constrained_noisy', f0n, imn[None], call, do_intermediates=False)
 
 
+def big_clusters():
+    """Clusters beyond the block kernel's 64 features / 127 variables (the engine's large-cluster
+    path; BASELINE cfg 3 at its stated density percolates into such clusters): one 2D cluster of
+    90 features (271 variables) and one 3D anisotropic cluster of 75 features (301 variables),
+    Poisson noise.  The reference's SLSQP needs seconds to minutes on these."""
+    import numpy as np
+    import pandas as pd
+    from clustertracking_amd import artificial
+    rng = np.random.RandomState(5)
+    size, ny, nx, sp = 3., 9, 10, 11.
+    im = np.zeros((int(sp * (ny + 1)), int(sp * (nx + 1))), np.uint8)
+    truth = np.array([[sp * (1 + gy), sp * (1 + gx)] for gy in range(ny) for gx in range(nx)]) \
+        + rng.uniform(-1.5, 1.5, (ny * nx, 2))
+    for p in truth:
+        artificial.draw_gaussian(im, p, size, 100)
+    im = artificial.add_poisson_noise(im, 10, rng)
+    p0 = truth + rng.uniform(-0.5, 0.5, truth.shape)
+    mg.save_case('big_cluster_2d', mg.table(p0, size, 90., 5., 2, True), im[None],
+                 dict(diameter=13), do_intermediates=False)
+
+    rng = np.random.RandomState(6)
+    size3, sp3, grid = (2., 4., 4.), (7., 13., 13.), (3, 5, 5)
+    shape = tuple(int(s * (g + 1)) for s, g in zip(sp3, grid))
+    im = np.zeros(shape, np.uint8)
+    truth = np.array([[sp3[0] * (1 + gz), sp3[1] * (1 + gy), sp3[2] * (1 + gx)]
+                      for gz in range(grid[0]) for gy in range(grid[1]) for gx in range(grid[2])]) \
+        + rng.uniform(-1., 1., (grid[0] * grid[1] * grid[2], 3))
+    for p in truth:
+        artificial.draw_gaussian(im, p, size3, 100)
+    im = artificial.add_poisson_noise(im, 10, rng)
+    p0 = truth + rng.uniform(-0.5, 0.5, truth.shape)
+    mg.save_case('big_cluster_3d', mg.table(p0, size3, 90., 5., 3, False), im[None],
+                 dict(diameter=[9, 17, 17]), do_intermediates=False)
+
+
 def main(only=None):
     if only is None or 'tetramer2d' in only:
         tetramer2d()
+    if only is None or 'big_clusters' in only:
+        big_clusters()
     for name, seed in HARD.items():
         if only is not None and name not in only:
             continue
