@@ -34,7 +34,7 @@ STATUS_TEXT = {
     2: 'non-finite initial parameters',
     3: 'solver did not converge',
     4: 'rms deviation of the fit is more than max_rms_dev',
-    5: 'cluster is beyond the engine (a feature with more than 32 overlapping neighbours)',
+    5: 'cluster is beyond the engine (a feature with more than 48 overlapping neighbours)',
 }
 
 

@@ -47,7 +47,7 @@ struct KernelInfo {
 };
 
 // ---- workspace of one large cluster (large_kernel.h), in doubles ---------------------------
-constexpr int LARGE_MAXNB = 32;   // neighbours (features with overlapping mask boxes) per feature
+constexpr int LARGE_MAXNB = 48;   // neighbours (features with overlapping mask ellipsoids) per feature
 
 struct LargeWs {
   long long nvp, nvp_i;   // variables / features rounded up to a multiple of 8

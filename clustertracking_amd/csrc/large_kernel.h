@@ -65,6 +65,10 @@ __device__ __forceinline__ bool wg_any(bool x, double* red, int lane, int wave) 
   return __syncthreads_or(x ? 1 : 0) != 0;
 }
 
+// diagnostic counters (tests/tools/run_cfg3.py via ctr_debug_large_counters): [0] linear
+// solves, [1] conjugate-gradient iterations, [2] pixel passes
+__device__ unsigned long long g_large_dbg[8];   // [4] ticks (100 MHz) in pixel passes, [5] in solves
+
 template <int ND, bool ISO>
 __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double* __restrict__ ws_base,
                                                           const long long* __restrict__ ws_off) {
@@ -90,8 +94,8 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
   const LargeWs W = large_ws(n, NPF, NS);
   double* ws = ws_base + ws_off[cl];
   double *v = ws + W.o_vec, *vt = v + W.nvp, *v0 = vt + W.nvp, *lo = v0 + W.nvp, *hi = lo + W.nvp,
-         *g = hi + W.nvp, *xs = g + W.nvp, *rs = xs + W.nvp, *zs = rs + W.nvp, *ps = zs + W.nvp,
-         *Aps = ps + W.nvp, *dl = Aps + W.nvp, *Dm = dl + W.nvp, *fre = Dm + W.nvp;
+         *g = hi + W.nvp, *xs = g + W.nvp, *rs_g = xs + W.nvp, *zs_g = rs_g + W.nvp, *ps_g = zs_g + W.nvp,
+         *Aps_g = ps_g + W.nvp, *dl = Aps_g + W.nvp, *Dm = dl + W.nvp, *fre = Dm + W.nvp;
   double *cur = ws + W.o_cur, *mco = ws + W.o_mco, *fpar = ws + W.o_fpar, *pre = ws + W.o_pre,
          *uq = ws + W.o_uq;
   double* tileA = ws + W.o_tile;                 // accepted point
@@ -490,8 +494,9 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
     Pout = (int)pv[0];
   };
 
-  // y = (B + mu diag(Dm)) x on the variables with mk != nullptr ? mk == 1 : all; B = J^T J of
-  // (tile, off) plus, with use_q, the second-order entries uq.  Returns x^T y (all threads).
+  // y = (B + mu diag(Dm)) x, rows of fixed variables zeroed when mk != nullptr (x is expected to
+  // be zero there already); B = J^T J of (tile, off) plus, with use_q, the second-order entries
+  // uq.  One matrix row per thread at a time (n NPF rows over 1024 threads).  Returns x^T y.
   auto matvec = [&](const double* x, double* y, const double* tile, const double* off, double muv,
                     bool use_q, const double* mk) -> double {
     __syncthreads();
@@ -500,64 +505,51 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
     for (int q = 0; q < 9; ++q) part[q] = 0.;
     double xsh[8];
 #pragma unroll
-    for (int kq = 0; kq < 8; ++kq) xsh[kq] = kq < NS ? x[kq] * (mk ? mk[kq] : 1.) : 0.;
-    for (int i = tid; i < n; i += LT) {
+    for (int kq = 0; kq < 8; ++kq) xsh[kq] = kq < NS ? x[kq] : 0.;
+    const int nrows = n * NPF;
+    for (int r = tid; r < nrows; r += LT) {
+      const int i = r / NPF, a = r - i * NPF;
       const int b0 = NS + i * NPF;
-      const double* t = tile + (size_t)i * 256;
-      double xi[MAXPF], yi[MAXPF];
+      const double* t = tile + (size_t)i * 256 + (c_own + a) * 16;
+      const double xa = x[b0 + a];
+      double s = muv * Dm[b0 + a] * xa;
 #pragma unroll
-      for (int a = 0; a < MAXPF; ++a) { xi[a] = a < NPF ? x[b0 + a] * (mk ? mk[b0 + a] : 1.) : 0.; yi[a] = 0.; }
+      for (int b = 0; b < MAXPF; ++b)
+        if (b < NPF) s += t[c_own + b] * x[b0 + b];
 #pragma unroll
-      for (int a = 0; a < MAXPF; ++a) {
-        if (a >= NPF) continue;
-        double s = muv * Dm[b0 + a] * xi[a];
-#pragma unroll
-        for (int b = 0; b < MAXPF; ++b)
-          if (b < NPF) s += t[(c_own + a) * 16 + c_own + b] * xi[b];
-#pragma unroll
-        for (int kq = 0; kq < 8; ++kq)
-          if (kq < NS) s += t[(c_own + a) * 16 + 1 + kq] * xsh[kq];
-        yi[a] = s;
-      }
+      for (int kq = 0; kq < 8; ++kq)
+        if (kq < NS) { s += t[1 + kq] * xsh[kq]; part[1 + kq] += t[1 + kq] * xa; }
       if (use_q) {
         // second-order part between (signal, positions) of this feature
         const double* u = uq + (size_t)i * 16;
+        int ka = -1;
 #pragma unroll
-        for (int a = 0; a < MAXPF; ++a)
+        for (int q = 0; q < MAXPF; ++q) ka = q == a ? kind_of[q] : ka;
+        if (ka >= 0) {
 #pragma unroll
           for (int b = 0; b < MAXPF; ++b) {
-            if (a >= NPF || b >= NPF) continue;
-            const int ka = kind_of[a], kb = kind_of[b];
-            if (ka < 0 || kb < 0 || ka + kb == 0) continue;
+            if (b >= NPF) continue;
+            const int kb = kind_of[b];
+            if (kb < 0 || ka + kb == 0) continue;
             const int k0 = ka < kb ? ka : kb, k1 = ka < kb ? kb : ka;
             const int e = k0 == 0 ? k1 - 1 : ND + ((k0 - 1) * ND - ((k0 - 1) * (k0 - 2)) / 2 + (k1 - k0));
-            yi[a] += u[e] * xi[b];
+            s += u[e] * x[b0 + b];
           }
-      }
-      const int cnt = nbcnt[i];
-      for (int s2 = 0; s2 < cnt; ++s2) {
-        const int j = nbidx[(size_t)i * LARGE_MAXNB + s2];
-        const double* o = off + ((size_t)i * LARGE_MAXNB + s2) * 64;
-        const int bj = NS + j * NPF;
-#pragma unroll
-        for (int b = 0; b < MAXPF; ++b) {
-          if (b >= NPF) continue;
-          const double xj = x[bj + b] * (mk ? mk[bj + b] : 1.);
-#pragma unroll
-          for (int a = 0; a < MAXPF; ++a)
-            if (a < NPF) yi[a] += o[a * 8 + b] * xj;
         }
       }
+      const int cnt = nbcnt[i];
+      const int* nb = nbidx + (size_t)i * LARGE_MAXNB;
+      const double* o = off + (size_t)i * LARGE_MAXNB * 64 + a * 8;
+      for (int s2 = 0; s2 < cnt; ++s2) {
+        const double* xj = x + NS + nb[s2] * NPF;
+        const double* ob = o + s2 * 64;
 #pragma unroll
-      for (int a = 0; a < MAXPF; ++a) {
-        if (a >= NPF) continue;
-        const double ya = yi[a] * (mk ? mk[b0 + a] : 1.);
-        y[b0 + a] = ya;
-        part[0] += xi[a] * ya;
-#pragma unroll
-        for (int kq = 0; kq < 8; ++kq)
-          if (kq < NS) part[1 + kq] += t[(c_own + a) * 16 + 1 + kq] * xi[a];
+        for (int b = 0; b < MAXPF; ++b)
+          if (b < NPF) s += ob[b] * xj[b];
       }
+      s *= mk ? mk[b0 + a] : 1.;
+      y[b0 + a] = s;
+      part[0] += xa * s;
     }
     wg_sum(part, 1 + NS, red, lane, wave);
     double dot = part[0];
@@ -610,16 +602,20 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         wshape[a] = (int)(u - l);
       }
     }
-    // neighbour lists: features whose mask boxes overlap (a superset of overlapping masks)
+    // neighbour lists: features whose mask ellipsoids (same semi-axes, the radius) overlap --
+    // scaled centre distance <= 2; the masks are pixel subsets of the ellipsoids
     bool overflow = false;
     for (int i = tid; i < n; i += LT) {
       int cnt = 0;
       for (int j = 0; j < n; ++j) {
         if (j == i) continue;
-        bool near = true;
+        double s2 = 0.;
 #pragma unroll
-        for (int a = 0; a < ND; ++a) near = near && fabs(mco[i * 3 + a] - mco[j * 3 + a]) <= 2. * radius[a] + 1e-9;
-        if (near) {
+        for (int a = 0; a < ND; ++a) {
+          const double t = (mco[i * 3 + a] - mco[j * 3 + a]) / (2. * radius[a]);
+          s2 += t * t;
+        }
+        if (s2 <= 1. + 1e-9) {
           if (cnt < LARGE_MAXNB) nbidx[(size_t)i * LARGE_MAXNB + cnt] = j;
           ++cnt;
         }
@@ -658,7 +654,9 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       bool accept = false;
       if (need_eval) {
         int P = 0;
+        const unsigned long long te0 = __builtin_amdgcn_s_memrealtime();
         evaluate(tileT, offT, par(vt, 0, 0), P);
+        if (tid == 0) { atomicAdd(&g_large_dbg[2], 1ull); atomicAdd(&g_large_dbg[4], __builtin_amdgcn_s_memrealtime() - te0); }
         double St = tot[c_reso * 16 + c_reso];
         if (bad_size) St = NAN;
         if (first) {
@@ -873,6 +871,13 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
           return acc2;
         };
         // ---- conjugate gradients on the free variables: (B + mu D) x = g ----------------------
+        // r, z, p, A p live in LDS while they fit (the row tiles are idle during a solve)
+        const unsigned long long tc0 = __builtin_amdgcn_s_memrealtime();
+        const bool cg_lds = 4 * W.nvp <= LW * WAVE * LRS;
+        double* rs = cg_lds ? smem + SmemL::o_rows : rs_g;
+        double* zs = cg_lds ? rs + W.nvp : zs_g;
+        double* ps = cg_lds ? zs + W.nvp : ps_g;
+        double* Aps = cg_lds ? ps + W.nvp : Aps_g;
         for (int i = tid; i < nv; i += LT) { xs[i] = 0.; rs[i] = g[i] * fre[i]; }
         // (a thread touches the entries of "its" features in every phase; the shared entries are
         //  thread 0's -- so only the matrix products and the sums need the barriers)
@@ -882,8 +887,12 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         for (int i = tid; i < nv; i += LT) ps[i] = zs[i];
         const double rz0 = rz[0];
         bool cg_fail = !(rz0 >= 0.) || !isfinite(rz0);
-        const int cg_max = nv + 50;
-        for (int ci = 0; ci < cg_max && !cg_fail && rz[0] > 1e-26 * rz0 && rz[0] > 0.; ++ci) {
+        // to a relative residual of 1e-11 in the preconditioned norm (the step of an LM iteration
+        // need not be more exact; the convergence test looks at steps of 1e-9 relative size)
+        const int cg_max = nv < 400 ? nv + 20 : 420;
+        int cg_it = 0;
+        for (int ci = 0; ci < cg_max && !cg_fail && rz[0] > 1e-22 * rz0 && rz[0] > 0.; ++ci) {
+          ++cg_it;
           const double pAp = matvec(ps, Aps, tl, ol, mu, nwt, fre);
           if (!(pAp > 0.) || !isfinite(pAp)) { cg_fail = true; break; }   // not positive definite
           const double alpha = rz[0] / pAp;
@@ -906,6 +915,11 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
             }
           if (tid == 0)
             for (int a = 0; a < NS; ++a) ps[a] = zs[a] + beta * ps[a];
+        }
+        if (tid == 0) {
+          atomicAdd(&g_large_dbg[0], 1ull);
+          atomicAdd(&g_large_dbg[1], (unsigned long long)cg_it);
+          atomicAdd(&g_large_dbg[5], __builtin_amdgcn_s_memrealtime() - tc0);
         }
         if (cg_fail) continue;
         __syncthreads();

@@ -22,3 +22,13 @@ KernelInfo ctr_large_kernel(int ndim, int iso) {
   if (ndim == 2) return iso ? one<2, true>() : one<2, false>();
   return iso ? one<3, true>() : one<3, false>();
 }
+
+// diagnostic, not part of include/ctrefine.h: totals since the last reset
+extern "C" int ctr_debug_large_counters(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_large_dbg), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_large_dbg), z, sizeof z) != hipSuccess) return 1;
+  }
+  return 0;
+}

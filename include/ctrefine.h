@@ -30,7 +30,10 @@ extern "C" {
 #define CTR_ABI_VERSION 2
 #define CTR_MAX_NDIM 3
 #define CTR_MAX_PARAMS 8 /* background, signal, <=3 positions, <=3 sizes */
-#define CTR_MAX_VARS 127 /* optimiser variables per cluster (engine limit) */
+#define CTR_MAX_VARS 127 /* optimiser variables per cluster of the on-chip kernels; larger clusters
+                            (or more than 64 features) take the large-cluster path: normal matrix
+                            block-sparse in HBM, no limit on features or variables */
+#define CTR_MAX_NEIGHBOURS 48 /* large-cluster path: features whose mask ellipsoids overlap one feature's */
 
 /* error codes (return values) */
 enum {
@@ -76,7 +79,9 @@ enum {
   CTR_STATUS_NONFINITE = 2,     /* non-finite initial parameters (refine.py:356-357) */
   CTR_STATUS_NO_CONVERGENCE = 3,/* solver failed / iteration limit (refine.py:376-377) */
   CTR_STATUS_RMS_DEV = 4,       /* rms deviation above max_rms_dev (refine.py:391-394) */
-  CTR_STATUS_TOO_LARGE = 5      /* more than CTR_MAX_VARS variables (engine limit) */
+  CTR_STATUS_TOO_LARGE = 5      /* beyond the engine: a cluster of the large-cluster path in which a feature
+                                   has more than CTR_MAX_NEIGHBOURS overlapping neighbours, or whose
+                                   parameter modes leave no per-feature variable (reported as data) */
 };
 
 /* What is fitted and how (one per call). */
@@ -130,7 +135,8 @@ typedef struct ctr_batch {
                                   derivatives instead of finite differences.  NaN for constant
                                   parameters, failed clusters and a Hessian that is not positive
                                   definite.  Exact when the sizes are constant and signal and
-                                  positions per-feature variables (the default modes). */
+                                  positions per-feature variables (the default modes).  NaN for
+                                  clusters of the large-cluster path (> 64 features). */
 } ctr_batch;
 
 typedef struct ctr_handle ctr_handle;
@@ -140,7 +146,9 @@ typedef struct ctr_plan ctr_plan;
 int ctr_abi_version(void);
 
 /* Create / destroy an engine bound to one HIP device.  Owns streams and
- * scratch buffers.  One caller thread at a time per handle. */
+ * scratch buffers (frame maxima, work counters).  One caller thread at a time per handle; the
+ * *_device calls of one handle are ordered on the device (a call waits for the previous one of
+ * the same handle, whatever streams they were given): to overlap batches use one handle each. */
 int ctr_create(ctr_handle** out, int device);
 void ctr_destroy(ctr_handle* h);
 
@@ -159,7 +167,8 @@ int ctr_cluster_n_vars(const ctr_problem* p, int n_features);
 int ctr_refine_batch(ctr_handle* h, const ctr_problem* p, const ctr_batch* b);
 
 /* Device-resident path (inputs already in HBM, e.g. frames produced on the
- * GPU): a plan bins the clusters of a batch by problem size on the host once;
+ * GPU): a plan bins the clusters of a batch by problem size on the host once (and owns the
+ * HBM workspace of its large clusters: use a plan with the handle it was created on);
  * the run is asynchronous on the given HIP stream (hipStream_t passed as
  * void*; NULL = the handle's own stream). */
 int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,

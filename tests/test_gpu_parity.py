@@ -253,8 +253,71 @@ def test_cfg5_dense_clusters_and_dimers_vs_oracle(engine, oracle):
         assert abs(np.sqrt(((p[0] - p[1]) ** 2).sum()) - 6.) < 1e-8
 
 
+def _grid_cluster(ny, nx, spacing, seed, size=3.):
+    """ny x nx features on a jittered grid closer than the separation: one cluster"""
+    rng = np.random.RandomState(seed)
+    im = np.zeros((int(spacing * (ny + 1)), int(spacing * (nx + 1))), np.uint8)
+    truth = np.array([[spacing * (1 + gy), spacing * (1 + gx)] for gy in range(ny) for gx in range(nx)]) \
+        + rng.uniform(-1.5, 1.5, (ny * nx, 2))
+    for p in truth:
+        cta.artificial.draw_gaussian(im, p, size, 100)
+    im = cta.artificial.add_poisson_noise(im, 10, rng)
+    f0 = pd.DataFrame(truth + rng.uniform(-0.5, 0.5, truth.shape), columns=['y', 'x'])
+    f0['signal'], f0['size'], f0['background'] = 90., size, 5.
+    return im, f0, truth
+
+
+@pytest.mark.parametrize("mode", [None, dict(size='var'), dict(signal='cluster'),
+                                  dict(size='cluster', background='const')])
+def test_large_cluster_path_vs_oracle(engine, oracle, mode):
+    """Clusters beyond the block kernel (> 64 features): refine_large_kernel (block-sparse normal
+    matrix in HBM, conjugate gradients) against the oracle (dense Cholesky), several parameter
+    modes.  The reference-generated fixtures big_cluster_2d / _3d pin the default modes."""
+    im, f0, truth = _grid_cluster(8, 11, 11., 3)
+    prep = cta.prepare_batch(f0, im, 13, param_mode=mode)
+    assert prep.batch.n_clusters == 1 and prep.batch.n_features == 88
+    ref = clone_batch(prep.batch)
+    engine.refine_batch(prep.problem, prep.batch)
+    oracle.run_batch(prep.problem, ref, n_threads=4)
+    assert_batches_close(prep.batch, ref, slice(2, 4), atol=1e-6)
+    assert prep.batch.status[0] == 0
+    rms = np.sqrt(np.mean((prep.batch.params_out[:, 2:4] - truth[prep.order]) ** 2))
+    assert rms < 0.05, rms
+
+
+def test_cfg3_at_its_stated_density(engine):
+    """BASELINE cfg 3 as specified: 500 features per 64x128x128 stack percolate into ONE cluster
+    of 500 features (2001 variables).  Stack 0 against the oracle's stored result
+    (tests/golden/make_golden_cfg3.py: the oracle needs ~8 minutes for it, the GPU seconds);
+    a second stack by the size-independent properties."""
+    import hashlib
+    frames, f0, truth, opts = workloads.cfg3(2, 0, n_features=500)
+    prep = cta.prepare_batch(f0, cta.ArrayReader(frames), opts['diameter'])
+    b = prep.batch
+    sizes = np.diff(b.feat_offset)
+    assert sizes.max() == 500
+    engine.refine_batch(prep.problem, b)
+    assert (b.status == 0).all(), b.status
+    out = np.empty_like(b.params_out)
+    out[prep.order] = b.params_out
+    rms = np.sqrt(np.mean((out[:, 2:5] - truth) ** 2))
+    assert rms < 0.1, rms           # dense overlap at S/N 10 (tests/test_refine.py:41 bar for S/N 3)
+    z = np.load(os.path.join(_cases.GOLDEN, 'cfg3_500_oracle.npz'))
+    one = cta.prepare_batch(f0[f0['frame'] == 0].copy(), cta.ArrayReader(frames), opts['diameter'])
+    digest = hashlib.sha256(frames[:1].tobytes() + np.ascontiguousarray(one.batch.params).tobytes()).hexdigest()
+    assert digest == str(z['digest']), "workloads.cfg3 no longer regenerates the stored inputs"
+    n0 = int(z['feat_offset'][-1])
+    assert_equal(b.feat_offset[:len(z['feat_offset'])], z['feat_offset'])
+    assert_equal(b.status[:len(z['status'])], z['status'])
+    assert_equal(b.n_rounds[:len(z['status'])], z['n_rounds'])
+    assert_allclose(b.cost[:len(z['status'])], z['cost'], rtol=1e-9)
+    assert np.abs(b.params_out[:n0, 2:5] - z['params_out'][:, 2:5]).max() < 1e-6
+    assert_allclose(b.params_out[:n0], z['params_out'], rtol=1e-6, atol=1e-6)
+
+
 def test_too_large_cluster_is_data_not_error(engine):
-    """More features than the engine holds in one wave -> status 5, NaN cost."""
+    """A feature with more overlapping neighbours than the large-cluster path keeps
+    (CTR_MAX_NEIGHBOURS) -> status 5, NaN cost."""
     n = 70
     im = np.zeros((64, 64), np.uint8)
     p0 = np.column_stack([np.full(n, 32.), np.linspace(20, 44, n)])
