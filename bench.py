@@ -50,6 +50,10 @@ def parse():
                     help="run the N > 1 code path (process group, staging, asynchronous gather) with one rank")
     ap.add_argument('--shard', type=int, default=None,
                     help="rehearsal on one GPU: take the frames rank SHARD of a multi-GPU run would get")
+    ap.add_argument('--device-frames', action='store_true',
+                    help="cfg2: draw the frames ON THE DEVICE from the seeds' truth positions "
+                         "(ctr_draw_frames_device; the Poisson noise is then the engine's own generator, "
+                         "not NumPy's: same statistics, other bytes)")
     ap.add_argument('--single-device', action='store_true',
                     help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
@@ -155,6 +159,19 @@ def main():
         extra['constraints'] = cta.constraints.dimer(6., 2)
         wl_text = ("cfg5: %d frames/GPU of 512x512 uint8, 36 compact clusters of 2/8-16 Gaussians, "
                    "size 3, diameter 13, dimers constrained to 2*size" % args.frames)
+    if args.device_frames:
+        if args.workload != 'cfg2':
+            raise SystemExit("--device-frames is implemented for cfg2")
+        from clustertracking_amd.device import draw_frames
+        t0 = time.perf_counter()
+        dev_frames = draw_frames(frames.shape[1:], f0['frame'].values.astype(np.int32), truth, 3., 100.,
+                                 n_frames=frames.shape[0], noise=10., seed=12345 + shard, device=local_rank)
+        torch.cuda.synchronize()
+        extra_info = {"frames_drawn_on_device_s": time.perf_counter() - t0}
+        frames = dev_frames.cpu().numpy()       # (the host copy feeds prepare_batch and the CPU legs)
+        wl_text += "; frames drawn on the device (ctr_draw_frames_device)"
+    else:
+        extra_info = {}
     reader = cta.ArrayReader(frames)
     t0 = time.perf_counter()
     prep = cta.prepare_batch(f0, reader, opts['diameter'], **extra)
@@ -335,6 +352,7 @@ def main():
                                    "note": "flops_it = sum p(6d+8) + P nv(nv+1) + 2 P nv + 2P + nv^3/3 per solver "
                                            "iteration (SURVEY.md 8d), P = n p; x the measured n_iter of every cluster"},
             "host_prepare_s": t_host_prep,
+            **extra_info,
             "gather_checked": gather_ok,
             "batches_in_flight": nfl,
             "in_flight_results_identical": copies_same,

@@ -65,6 +65,16 @@ class Batch(C.Structure):
     ]
 
 
+class Synth(C.Structure):
+    """``ctr_synth`` (include/ctrefine.h): synthetic frames on the device."""
+    _fields_ = [
+        ('ndim', C.c_int32), ('frame_dtype', C.c_int32), ('n_frames', C.c_int64),
+        ('shape', C.c_int64 * MAX_NDIM), ('n_features', C.c_int64),
+        ('frame_of', C.c_void_p), ('pos', C.c_void_p), ('size', C.c_void_p),
+        ('max_value', C.c_void_p), ('noise', C.c_double), ('seed', C.c_uint64),
+    ]
+
+
 def make_problem(ndim, isotropic, modes, radius, constraint=None, max_iter=10,
                  max_shift=1., max_rms_dev=1., residual_factor=100000.,
                  solver_maxiter=100, xtol=0., ftol=0.):

@@ -17,7 +17,8 @@ EXPORTS = ('ctr_abi_version', 'ctr_create', 'ctr_destroy', 'ctr_last_error',
            'ctr_validate_problem', 'ctr_cluster_n_vars', 'ctr_refine_batch',
            'ctr_plan_create', 'ctr_plan_destroy', 'ctr_refine_batch_device',
            'ctr_frame_max_device', 'ctr_synchronize', 'ctr_last_kernel_ms',
-           'ctr_find_clusters', 'ctr_engine_wait_stream', 'ctr_stream_wait_engine')
+           'ctr_find_clusters', 'ctr_engine_wait_stream', 'ctr_stream_wait_engine',
+           'ctr_draw_frames_device')
 
 _lib = None
 _lock = threading.Lock()
@@ -101,6 +102,8 @@ def load():
             if hasattr(lib, name):   # (absent from libraries built before they existed)
                 getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(lib, name).restype = C.c_int
+        lib.ctr_draw_frames_device.argtypes = [C.c_void_p, P(_abi.Synth), C.c_void_p, C.c_void_p]
+        lib.ctr_draw_frames_device.restype = C.c_int
         lib.ctr_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_double), P(C.c_double)]
         lib.ctr_last_kernel_ms.restype = C.c_int
         if lib.ctr_abi_version() != _abi.ABI_VERSION:
@@ -183,6 +186,11 @@ class Engine(object):
                                                 labels.ctypes.data, sizes.ctypes.data),
                     'ctr_find_clusters')
         return labels, sizes
+
+    def draw_frames_device(self, synth, frames_ptr, stream=None):
+        """``ctr_draw_frames_device``: ``synth`` is an ``_abi.Synth`` with device pointers."""
+        self._check(self._lib.ctr_draw_frames_device(self._h, C.byref(synth), C.c_void_p(frames_ptr),
+                                                     C.c_void_p(stream or 0)), 'ctr_draw_frames_device')
 
     def synchronize(self, stream=None):
         self._check(self._lib.ctr_synchronize(self._h, C.c_void_p(stream or 0)),

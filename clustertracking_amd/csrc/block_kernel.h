@@ -243,7 +243,10 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP(slot) do {} while (0)
 #endif
 
-template <int ND, bool ISO, int NT, int W>
+// CONS: the instantiation that takes the clusters with equality constraints (dimers, trimers,
+// tetramers: at most 29 variables, NT <= 2); in the others the constrained code is compiled out
+// (it costs the unconstrained fits registers otherwise: 700 B of scratch per lane, measured).
+template <int ND, bool ISO, int NT, int W, bool CONS>
 __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
 #ifdef CTR_STAMPS
   unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
@@ -277,7 +280,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
   LayoutB L;
   make_layout_b(k.prob, n, L);
   const int nv = L.nv;
-  const int m = n_constraints(k.prob, n);
+  const int m = CONS ? n_constraints(k.prob, n) : 0;
   // the exact second-order terms need signal and positions as per-feature variables (the
   // default modes); otherwise the model Hessian is J^T J throughout (same rule: oracle solve())
   bool newton_on = L.slot[1] >= 0 && L.per_feat[1];
@@ -489,7 +492,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         for (int pass = 0; pass < 2; ++pass) {
           const unsigned long long fm = __ballot(!pinned);
           if (lane < m * m) {
-            const int r = lane / m, s2 = lane % m;
+            const int r = lane / (m > 0 ? m : 1), s2 = lane % (m > 0 ? m : 1);
             double t = 0.;
             for (unsigned long long q = fm; q != 0ull; q &= q - 1ull) {
               const int i = __builtin_ctzll(q);
@@ -914,7 +917,8 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
       if (phase == BP_EVAL_INIT) {
         if (P == 0) { status = CTR_STATUS_OUT_OF_BOUNDS; failed = true; }
         else if (!isfinite(St) || retr_fail) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
-        mu = 1e-3; nu = 2.; last_acc = true; gain = INFINITY;
+        // (a size among the variables: more damping at the start, see oracle solve())
+        mu = size_is_var ? 1. : 1e-3; nu = 2.; last_acc = true; gain = INFINITY;
         Pround = P;
         accept = !failed;
       } else if (phase == BP_EVAL_TRIAL) {
@@ -1000,7 +1004,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         if (m) {
           double* ry = cv + 18;
           if (lane < m * m) {
-            const int r = lane / m, s2 = lane % m;
+            const int r = lane / (m > 0 ? m : 1), s2 = lane % (m > 0 ? m : 1);
             double t = 0.;
             for (int i = 0; i < nv; ++i)
               if (lo[i] < hi[i]) t += Cj[r * LDC + i] * Cj[s2 * LDC + i];
@@ -1035,7 +1039,9 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             bool fre = false;
             if (i < nv) {
               double gl = Mp[tri(i + 1)];
-              for (int r = 0; r < m; ++r) gl += Cj[r * LDC + i] * mult0[r];
+#pragma unroll
+              for (int r = 0; r < MAXC; ++r)
+                if (r < m) gl += Cj[r * LDC + i] * mult0[r];
               const bool fixed = (lo[i] == hi[i]) || (v[i] <= lo[i] && gl > 0.) || (v[i] >= hi[i] && gl < 0.);
               fre = !fixed;
             }
@@ -1157,7 +1163,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
                   chol_solve_w(Hp, dl, nf, Y, m, LDC, lane);
                   // tangent step, range-space form: (C H^-1 C^T) mult = -C H^-1 g, so that C d = 0
                   if (lane < m * m) {
-                    const int r = lane / m, s2 = lane % m;
+                    const int r = lane / (m > 0 ? m : 1), s2 = lane % (m > 0 ? m : 1);
                     double t = 0.;
                     for (int a = 0; a < nf; ++a) t += Cj[r * LDC + fr[a]] * Y[s2 * LDC + a];
                     Sc[r * MAXC + s2] = t;

@@ -33,6 +33,7 @@ namespace {
 
 #include "device_common.h"
 #include "aux_kernels.h"
+#include "synth_kernels.h"
 
 // ---- host side ------------------------------------------------------------------------
 
@@ -47,8 +48,10 @@ std::mutex g_mutex;
 // bins: 0..MAXNT-1 generic kernel by NT-1; MAXNT = beyond the engine (see CTR_STATUS_TOO_LARGE);
 // MAXNT+1 / MAXNT+2 = singles / pairs with default modes (small kernel); MAXNT+3 = large
 // clusters (more than MAXF features or 16 MAXNT columns: refine_large_kernel)
+// MAXNT+4 / MAXNT+5 = clusters with equality constraints, NT = 1 / 2 (their own instantiation of
+// the block kernel)
 constexpr int BIN_TOO_LARGE = MAXNT, BIN_SMALL1 = MAXNT + 1, BIN_SMALL2 = MAXNT + 2, BIN_LARGE = MAXNT + 3,
-              NBINS = MAXNT + 4;
+              BIN_CONS1 = MAXNT + 4, BIN_CONS2 = MAXNT + 5, NBINS = MAXNT + 6;
 static_assert(NBINS <= 16, "FrontArgs (aux_kernels.h) holds 16 bins");
 constexpr int NSIDE = 4;  // side streams for concurrent bin launches
 constexpr int GATE_US = 20;  // head start of the block kernels over the small kernels (delay_kernel)
@@ -83,6 +86,8 @@ struct ctr_handle {
   size_t smem_bytes[2][2][MAXNT];
   int block_threads[2][2][MAXNT];
   bool attr_set[2][2][MAXNT] = {};
+  KernelInfo cons[2][2][2][2];       // [ndim-2][iso][throughput][nt-1]: constrained clusters
+  bool cons_attr[2][2][2][2] = {};
   kernel_fn table_tp[2][2][MAXNT];   // the same for CTR_FLAG_THROUGHPUT (fewest wavefronts)
   size_t smem_bytes_tp[2][2][MAXNT];
   int block_threads_tp[2][2][MAXNT];
@@ -247,8 +252,11 @@ int ctr_create(ctr_handle** out, int device) {
       h->small_table[di][ii][1] = ctr_small_kernel(2 + di, 2, ii, 64);
       h->large[di][ii] = ctr_large_kernel(2 + di, ii);
       for (int nt = 1; nt <= MAXNT; ++nt) {
-        const KernelInfo a = di == 0 ? ctr_block_kernel_2d(ii, nt, 0) : ctr_block_kernel_3d(ii, nt, 0);
-        const KernelInfo t = di == 0 ? ctr_block_kernel_2d(ii, nt, 1) : ctr_block_kernel_3d(ii, nt, 1);
+        const KernelInfo a = di == 0 ? ctr_block_kernel_2d(ii, nt, 0, 0) : ctr_block_kernel_3d(ii, nt, 0, 0);
+        const KernelInfo t = di == 0 ? ctr_block_kernel_2d(ii, nt, 1, 0) : ctr_block_kernel_3d(ii, nt, 1, 0);
+        if (nt <= 2)
+          for (int tp = 0; tp < 2; ++tp)
+            h->cons[di][ii][tp][nt - 1] = di == 0 ? ctr_block_kernel_2d(ii, nt, tp, 1) : ctr_block_kernel_3d(ii, nt, tp, 1);
         h->table[di][ii][nt - 1] = a.fn; h->smem_bytes[di][ii][nt - 1] = a.smem; h->block_threads[di][ii][nt - 1] = a.threads;
         h->table_tp[di][ii][nt - 1] = t.fn; h->smem_bytes_tp[di][ii][nt - 1] = t.smem; h->block_threads_tp[di][ii][nt - 1] = t.threads;
       }
@@ -306,6 +314,9 @@ int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
     if (n < 0) { delete plan; return fail(h, CTR_ERR_INVALID, "feat_offset must be non-decreasing"); }
     int bin;
     const bool constrained = (p->constraint_kind == CTR_CONS_DIMER && n == 2);
+    const bool any_cons = (p->constraint_kind == CTR_CONS_DIMER && n == 2) ||
+                          (p->constraint_kind == CTR_CONS_TRIMER && n == 3) ||
+                          (p->constraint_kind == CTR_CONS_TETRAMER && n == 4);
     if (n > 0x3fffffLL) bin = BIN_TOO_LARGE;
     else if (n > MAXF) bin = BIN_LARGE;
     else if (default_modes && n == 1) bin = BIN_SMALL1;
@@ -315,6 +326,7 @@ int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
       const int nt = (nv + 1 + 15) / 16;
       bin = nt > MAXNT ? BIN_LARGE : (nt < 1 ? 0 : nt - 1);
       if (bin < MAXNT && n > (16 * (bin + 1) < MAXF ? 16 * (bin + 1) : MAXF)) bin = BIN_LARGE;
+      if (any_cons && bin < 2) bin = bin == 0 ? BIN_CONS1 : BIN_CONS2;   // (at most 29 variables)
     }
     if (bin == BIN_LARGE) {
       // the large kernel's 16-column row: [r, shared.., own.., r_o, shared_o..]
@@ -474,6 +486,21 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
       HIP_TRY(h, hipLaunchKernel(fn, dim3((unsigned)cnt), dim3((unsigned)threads), kargs, bytes, pick_stream(false)));
     }
   }
+  for (int cb = 1; cb >= 0; --cb) {
+    const int bin = cb == 0 ? BIN_CONS1 : BIN_CONS2;
+    const int64_t cnt = plan->bin_count[bin];
+    if (cnt == 0) continue;
+    const int tp = ((p.flags & CTR_FLAG_THROUGHPUT) != 0 && p.ndim == 2) ? 1 : 0;
+    const KernelInfo& ki = h->cons[di][ii][tp][cb];
+    if (!h->cons_attr[di][ii][tp][cb]) {
+      HIP_TRY(h, hipFuncSetAttribute(ki.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ki.smem));
+      h->cons_attr[di][ii][tp][cb] = true;
+    }
+    k.order = ord + plan->bin_begin[bin];
+    k.n_bin = (int32_t)cnt;
+    void* kargs[] = {(void*)&k};
+    HIP_TRY(h, hipLaunchKernel(ki.fn, dim3((unsigned)cnt), dim3((unsigned)ki.threads), kargs, ki.smem, pick_stream(false)));
+  }
   if (plan->bin_count[BIN_LARGE] > 0) {
     // one 1024-thread workgroup per cluster, all of a CU's LDS: first in the queue
     const int64_t cnt = plan->bin_count[BIN_LARGE];
@@ -499,7 +526,7 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
   // the small kernels start a little later than the block kernels (see delay_kernel)
   bool gate = false;
   for (int bin = 0; bin < MAXNT; ++bin) gate = gate || plan->bin_count[bin] > 0;
-  gate = gate || plan->bin_count[BIN_LARGE] > 0;
+  gate = gate || plan->bin_count[BIN_LARGE] > 0 || plan->bin_count[BIN_CONS1] > 0 || plan->bin_count[BIN_CONS2] > 0;
   if (gate) {
     hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(WAVE), 0, s, (unsigned long long)GATE_US * 100ull);
     HIP_TRY(h, hipEventRecord(h->ev_gate, s));
@@ -613,6 +640,54 @@ int ctr_find_clusters(ctr_handle* h, int32_t ndim, const double* pos, const int3
   HIP_TRY(h, hipMemcpyAsync(label_out, d_label, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost, s));
   HIP_TRY(h, hipMemcpyAsync(size_out, d_size, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost, s));
   HIP_TRY(h, hipStreamSynchronize(s));
+  return CTR_OK;
+}
+
+int ctr_draw_frames_device(ctr_handle* h, const ctr_synth* sy, void* frames_out, void* hip_stream) {
+  if (!h || !sy || !frames_out) return CTR_ERR_INVALID;
+  if (sy->ndim != 2 && sy->ndim != 3) return fail(h, CTR_ERR_INVALID, "ndim must be 2 or 3");
+  if (sy->frame_dtype != CTR_DTYPE_U8 && sy->frame_dtype != CTR_DTYPE_U16)
+    return fail(h, CTR_ERR_UNSUPPORTED, "frames are drawn as uint8 or uint16 (integer wrap-around is part of the rule)");
+  if (sy->n_frames < 0 || sy->n_features < 0) return fail(h, CTR_ERR_INVALID, "negative counts");
+  if (!(sy->noise >= 0.)) return fail(h, CTR_ERR_INVALID, "noise must be >= 0");
+  long long felems = 1;
+  for (int a = 0; a < sy->ndim; ++a) {
+    if (sy->shape[a] < 1) return fail(h, CTR_ERR_INVALID, "frame shape must be positive");
+    felems *= sy->shape[a];
+  }
+  const long long total = felems * sy->n_frames;
+  if (total == 0) return CTR_OK;
+  if (sy->n_features > 0 && (!sy->frame_of || !sy->pos || !sy->size || !sy->max_value))
+    return fail(h, CTR_ERR_INVALID, "null feature table");
+  if (sy->n_features > 0x7fffffffLL) return fail(h, CTR_ERR_INVALID, "too many features for one launch");
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  int* acc = nullptr;
+  HIP_TRY(h, hipMallocAsync((void**)&acc, sizeof(int) * (size_t)total, s));
+  HIP_TRY(h, hipMemsetAsync(acc, 0, sizeof(int) * (size_t)total, s));
+  SynthArgs a;
+  a.ndim = sy->ndim;
+  for (int q = 0; q < 3; ++q) a.shape[q] = q < sy->ndim ? (long)sy->shape[q] : 1;
+  a.frame_elems = (long)felems;
+  a.n_features = (long)sy->n_features;
+  a.frame_of = sy->frame_of;
+  a.pos = sy->pos;
+  a.size = sy->size;
+  a.max_value = sy->max_value;
+  a.acc = acc;
+  if (sy->n_features > 0) {
+    if (sy->ndim == 2) hipLaunchKernelGGL(draw_features_kernel<2>, dim3((unsigned)sy->n_features), dim3(SYN_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(draw_features_kernel<3>, dim3((unsigned)sy->n_features), dim3(SYN_THREADS), 0, s, a);
+  }
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (sy->frame_dtype == CTR_DTYPE_U8)
+    hipLaunchKernelGGL(finish_frames_kernel<uint8_t>, dim3(blocks), dim3(256), 0, s, acc, (uint8_t*)frames_out,
+                       (long)total, sy->noise, (unsigned long long)sy->seed, 255L);
+  else
+    hipLaunchKernelGGL(finish_frames_kernel<uint16_t>, dim3(blocks), dim3(256), 0, s, acc, (uint16_t*)frames_out,
+                       (long)total, sy->noise, (unsigned long long)sy->seed, 65535L);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipFreeAsync(acc, s));
   return CTR_OK;
 }
 

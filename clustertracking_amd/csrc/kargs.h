@@ -75,9 +75,10 @@ __host__ __device__ inline LargeWs large_ws(int n, int npf, int ns) {
 }
 
 // refine_large_kernel<ND, ISO>(KArgs, double* ws, const long long* ws_off_of_cluster)
-// refine_block_kernel<ND, ISO, NT, W>: nt = 1..8; throughput != 0: the fewest wavefronts
-KernelInfo ctr_block_kernel_2d(int iso, int nt, int throughput);
-KernelInfo ctr_block_kernel_3d(int iso, int nt, int throughput);
+// refine_block_kernel<ND, ISO, NT, W, CONS>: nt = 1..8; throughput != 0: the fewest wavefronts;
+// cons != 0: the instantiation for clusters with equality constraints (nt = 1, 2 only)
+KernelInfo ctr_block_kernel_2d(int iso, int nt, int throughput, int cons);
+KernelInfo ctr_block_kernel_3d(int iso, int nt, int throughput, int cons);
 // refine_small_kernel<ND, NF, ISO, SG>(KArgs, int* counter); nullptr if not instantiated
 const void* ctr_small_kernel(int ndim, int nf, int iso, int sg);
 KernelInfo ctr_large_kernel(int ndim, int iso);

@@ -644,7 +644,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
     if (wg_any(infeasible, red, lane, wave)) { status = CTR_STATUS_NO_CONVERGENCE; break; }
     fill_fpar(vt, size_is_var || round == 0);
     it = 0;
-    mu = 1e-3; nu = 2.; last_acc = true; gain = INFINITY;
+    mu = size_is_var ? 1. : 1e-3; nu = 2.; last_acc = true; gain = INFINITY;   // (oracle solve())
 
     // ---- one solver run ------------------------------------------------------------------
     bool need_eval = true, first = true, converged = false, failed = false;

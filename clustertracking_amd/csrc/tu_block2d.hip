@@ -16,15 +16,20 @@ template <int NT> struct WavesFor { static constexpr int value = NT <= 2 ? 8 : (
 // for 3-4 features; two or three workgroups per CU instead of one for 5-30 features)
 template <int NT> struct WavesThroughput { static constexpr int value = NT <= 2 ? 2 : 1; };
 
-template <bool ISO, int NT, bool TP>
+template <bool ISO, int NT, bool TP, bool CONS = false>
 KernelInfo one() {
   constexpr int W = TP ? WavesThroughput<NT>::value : WavesFor<NT>::value;
   static_assert(SmemB<NT, W>::bytes <= LDS_CU, "LDS budget of one CU");
-  return KernelInfo{(const void*)refine_block_kernel<2, ISO, NT, W>, SmemB<NT, W>::bytes, WAVE * W};
+  return KernelInfo{(const void*)refine_block_kernel<2, ISO, NT, W, CONS>, SmemB<NT, W>::bytes, WAVE * W};
 }
 
 template <bool ISO, bool TP>
-KernelInfo by_nt(int nt) {
+KernelInfo by_nt(int nt, int cons) {
+  if (cons) {   // constrained clusters have at most 4 features = 29 variables
+    if (nt == 1) return one<ISO, 1, TP, true>();
+    if (nt == 2) return one<ISO, 2, TP, true>();
+    return KernelInfo{nullptr, 0, 0};
+  }
   switch (nt) {
     case 1: return one<ISO, 1, TP>();
     case 2: return one<ISO, 2, TP>();
@@ -40,9 +45,9 @@ KernelInfo by_nt(int nt) {
 
 }  // namespace
 
-KernelInfo ctr_block_kernel_2d(int iso, int nt, int throughput) {
-  if (throughput) return iso ? by_nt<true, true>(nt) : by_nt<false, true>(nt);
-  return iso ? by_nt<true, false>(nt) : by_nt<false, false>(nt);
+KernelInfo ctr_block_kernel_2d(int iso, int nt, int throughput, int cons) {
+  if (throughput) return iso ? by_nt<true, true>(nt, cons) : by_nt<false, true>(nt, cons);
+  return iso ? by_nt<true, false>(nt, cons) : by_nt<false, false>(nt, cons);
 }
 
 #ifdef CTR_STAMPS

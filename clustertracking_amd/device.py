@@ -93,3 +93,64 @@ class DeviceBatch(object):
         hb = self.host
         return int(hb.frames.nbytes + hb.n_features * 2 * hb.params.shape[1] * 8 +
                    hb.n_clusters * 16)
+
+
+def draw_frames(shape, frame_of, pos, size, max_value, n_frames=None, noise=0., seed=0,
+                dtype=np.uint8, device=0, engine=None):
+    """Synthetic frames drawn ON THE DEVICE (``ctr_draw_frames_device``): Gaussians by the
+    rule of reference ``artificial.draw_feature`` (artificial.py:131-141: truncated to the pixel
+    type, added with integer wrap-around) plus Poisson noise clipped to the pixel range
+    (artificial.py:368-378).  The noise-free bytes equal ``clustertracking_amd.artificial.
+    draw_gaussian``'s; the noise comes from the engine's own generator (same statistics as
+    NumPy's, other bytes).
+
+    shape: frame shape (z,) y, x; frame_of [N], pos [N, ndim], size scalar / [ndim] / [N, ndim],
+    max_value scalar / [N].  Returns a torch tensor [n_frames, *shape] on the device.
+    """
+    import torch
+    eng = engine or _lib.default_engine(device)
+    dev = torch.device('cuda', device)
+    ndim = len(shape)
+    pos = np.ascontiguousarray(np.asarray(pos, dtype=np.float64).reshape(-1, ndim))
+    n = len(pos)
+    frame_of = np.ascontiguousarray(np.broadcast_to(np.asarray(frame_of, dtype=np.int32), (n,)))
+    size = np.ascontiguousarray(np.broadcast_to(np.asarray(size, dtype=np.float64), (n, ndim)))
+    max_value = np.ascontiguousarray(np.broadcast_to(np.asarray(max_value, dtype=np.float64), (n,)))
+    if n_frames is None:
+        n_frames = int(frame_of.max()) + 1 if n else 0
+    if n and (frame_of.min() < 0 or frame_of.max() >= n_frames):
+        raise ValueError("frame index outside of the block")
+    if n and (np.any(pos < 0) or np.any(pos >= np.asarray(shape))):
+        raise ValueError("Position outside of image.")       # artificial.py:108-109
+    dt = np.dtype(dtype)
+    if dt not in (np.dtype(np.uint8), np.dtype(np.uint16)):
+        raise NotImplementedError("frames are drawn as uint8 or uint16")
+    if n and not np.all(max_value <= np.iinfo(dt).max):
+        raise ValueError("max_value exceeds the pixel type")
+    tdt = torch.uint8 if dt == np.uint8 else torch.int16
+    with torch.cuda.device(dev):
+        out = torch.empty((n_frames,) + tuple(shape), dtype=tdt, device=dev)
+        t_fo = torch.from_numpy(frame_of).to(dev)
+        t_pos = torch.from_numpy(pos).to(dev)
+        t_size = torch.from_numpy(size).to(dev)
+        t_mv = torch.from_numpy(max_value).to(dev)
+        sy = _abi.Synth()
+        sy.ndim = ndim
+        sy.frame_dtype = _abi.DTYPE_CODES[dt]
+        sy.n_frames = n_frames
+        for a, v in enumerate(shape):
+            sy.shape[a] = int(v)
+        sy.n_features = n
+        sy.frame_of, sy.pos, sy.size, sy.max_value = (t_fo.data_ptr(), t_pos.data_ptr(),
+                                                      t_size.data_ptr(), t_mv.data_ptr())
+        sy.noise = float(noise)
+        sy.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cur = torch.cuda.current_stream(dev)
+        if cur.cuda_stream != 0:
+            eng.draw_frames_device(sy, out.data_ptr(), cur.cuda_stream)
+            cur.synchronize()            # the inputs above must outlive the kernels
+        else:
+            eng.engine_wait_stream(0)
+            eng.draw_frames_device(sy, out.data_ptr(), 0)
+            eng.synchronize()
+    return out

@@ -193,6 +193,31 @@ int ctr_frame_max_device(ctr_handle* h, const void* frames, int32_t frame_dtype,
 int ctr_find_clusters(ctr_handle* h, int32_t ndim, const double* pos, const int32_t* frame_offset,
                       int64_t n_frames, const double* separation, int32_t* label_out, int32_t* size_out);
 
+/* Synthetic frames on the device (the generator next to the hot path):
+ * the drawing rule of reference artificial.draw_feature for the Gaussian (artificial.py:131-141:
+ * patch [max(floor(c - 4 size), 0), min(ceil(c + 4 size + 1), lim)) per axis,
+ * spot = max_value exp(-ndim/2 sum(((idx - c) / size)^2)), TRUNCATED to the pixel type and added
+ * with integer wrap-around) and the noise rule of SimulatedImage.noisy_image (:368-378: Poisson
+ * noise per pixel, clipped to the pixel type's range).  The noise-free bytes equal the
+ * reference rule's; the noise comes from the engine's own counter-based generator (seed, pixel
+ * index): same statistics as NumPy's, not the same bytes.  A feature whose centre lies outside
+ * its frame is skipped (the reference raises ValueError: check on the host).
+ * Device pointers; asynchronous on `hip_stream` (NULL = the handle's stream). */
+typedef struct ctr_synth {
+  int32_t ndim;                /* 2 or 3 */
+  int32_t frame_dtype;         /* CTR_DTYPE_U8 or CTR_DTYPE_U16 */
+  int64_t n_frames;
+  int64_t shape[CTR_MAX_NDIM]; /* (z,) y, x */
+  int64_t n_features;
+  const int32_t* frame_of;     /* [N] frame of each feature */
+  const double* pos;           /* [N, ndim] centres (z,) y, x */
+  const double* size;          /* [N, ndim] radius of gyration per axis (fitfunc.py:112-113) */
+  const double* max_value;     /* [N] peak value */
+  double noise;                /* Poisson level per pixel, 0 = none */
+  uint64_t seed;               /* of the noise */
+} ctr_synth;
+int ctr_draw_frames_device(ctr_handle* h, const ctr_synth* s, void* frames_out, void* hip_stream);
+
 /* Block until the work queued by the *_device calls on `hip_stream` is done. */
 int ctr_synchronize(ctr_handle* h, void* hip_stream);
 

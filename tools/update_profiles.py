@@ -1,25 +1,43 @@
-"""Turn what tools/profile_all.sh left under gpurun_out/v5_* into the files of profiles/
-(r01_v5_*: kernel stats, bench lines, counters per launch, traffic_cfg2.json)."""
-import csv, glob, json, os, shutil
+"""Turn what tools/profile_r2.sh left under gpurun_out/<round>/ into the files of profiles/
+(<round>_*: kernel stats with 8 batches in flight and with one, bench lines, counters per launch,
+traffic_cfg2.json, valu_cfg2.json).
+
+    python tools/update_profiles.py r02
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 os.chdir(ROOT)
+RND = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+SRC = 'gpurun_out/%s' % RND
 
 
 def latest(pat):
     return sorted(glob.glob(pat), key=os.path.getmtime)[-1]
 
 
-rows_out, tot = [], {}
-for cname, d in (('FETCH_SIZE', 'v5_pmc_fetch'), ('WRITE_SIZE', 'v5_pmc_write')):
-    rows = list(csv.DictReader(open(latest('gpurun_out/%s/*/*counter_collection.csv' % d))))
-    per = {}
-    for r in rows:
-        per.setdefault(r['Kernel_Name'], []).append(float(r['Counter_Value']))
+def per_kernel(counter_dir):
+    """{counter: {kernel: [values per launch]}} of one rocprofv3 --pmc pass"""
+    out = {}
+    for r in csv.DictReader(open(latest('%s/%s/*/*counter_collection.csv' % (SRC, counter_dir)))):
+        out.setdefault(r['Counter_Name'], {}).setdefault(r['Kernel_Name'], []).append(float(r['Counter_Value']))
+    return out
+
+
+# ---- HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes, 8 batches in flight, 1 step) -------
+tot = {}
+rows_out = []
+for cname, d in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
+    per = per_kernel(d)[cname]
+    tot[cname] = per
     for k, v in per.items():
         rows_out.append((cname, k, len(v), sum(v) / len(v)))
-    tot[cname] = per
-with open('profiles/r01_v5_pmc_per_launch.csv', 'w') as fo:
+with open('profiles/%s_pmc_per_launch.csv' % RND, 'w') as fo:
     fo.write('counter,kernel,launches,mean_value_KB\n')
     for o in rows_out:
         fo.write('%s,"%s",%d,%.3f\n' % o)
@@ -37,18 +55,59 @@ f, w = step_total('FETCH_SIZE'), step_total('WRITE_SIZE')
 fm_f = [sum(v) / len(v) for k, v in tot['FETCH_SIZE'].items() if 'frame_max_kernel' in k][0]
 fm_w = [sum(v) / len(v) for k, v in tot['WRITE_SIZE'].items() if 'frame_max_kernel' in k][0]
 t = json.load(open('profiles/traffic_cfg2.json'))
+t['profile'] = 'profiles/%s_pmc_per_launch.csv' % RND
+t['source'] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (profiles/%s_pmc_per_launch.csv), "
+               "per launch; tools/profile_r2.sh" % RND)
 t['frame_max_kernel'].update(FETCH_SIZE_KB=fm_f, WRITE_SIZE_KB=fm_w, bytes_corrected=(2 * fm_f + fm_w) * 1024)
 t['refine_kernels'].update(FETCH_SIZE_KB=f, WRITE_SIZE_KB=w, bytes_corrected=(2 * f + w) * 1024)
-t['refine_kernels']['kernels'] = ("the kernels of one step with CTR_FLAG_THROUGHPUT (bench default): front_load, "
-                                  "refine_small_kernel<2,1,true,8>, <2,2,true,64> and <2,2,true,16>, "
-                                  "refine_block_kernel<2,true,1,2> and <2,true,2,2>")
 json.dump(t, open('profiles/traffic_cfg2.json', 'w'), indent=1)
-shutil.copy(latest('gpurun_out/v5_prof/*/*kernel_stats.csv'), 'profiles/r01_v5_kernel_stats.csv')
-for fn, o in (('v5_bench', 'r01_v5_bench.json'), ('v5_bench_cfg5', 'r01_v5_bench_cfg5.json'),
-              ('v5_bench_cfg3', 'r01_v5_bench_cfg3.json')):
-    line = open('gpurun_out/%s.json' % fn).read().strip().splitlines()[-1]
+
+# ---- SQ / GRBM counters, one batch at a time (five passes) -----------------------------------------
+sq = {}
+for i in range(1, 6):
+    for cname, per in per_kernel('pmc_sq%d' % i).items():
+        sq[cname] = {k: sum(v) / len(v) for k, v in per.items() if 'refine_' in k or 'frame_max_kernel' in k}
+kernels = sorted({k for per in sq.values() for k in per})
+with open('profiles/%s_pmc_sq_per_launch.csv' % RND, 'w') as fo:
+    fo.write('Counter_Name,' + ','.join('"%s"' % k for k in kernels) + '\n')
+    for cname in sorted(sq):
+        fo.write(cname + ',' + ','.join('%.1f' % sq[cname].get(k, 0.) for k in kernels) + '\n')
+
+bench1 = json.loads(open('%s/bench_inflight1.json' % SRC).read().strip().splitlines()[-1])
+refine = [k for k in kernels if 'refine_' in k]
+valu_insts = sum(sq['SQ_INSTS_VALU'].get(k, 0.) for k in refine)
+active = sum(sq['SQ_ACTIVE_INST_VALU'].get(k, 0.) for k in refine)      # quad-cycles, summed over SIMDs
+mfma_busy = sum(sq['SQ_VALU_MFMA_BUSY_CYCLES'].get(k, 0.) for k in refine)
+step_s = bench1['roofline']['kernel_ms_one_batch_alone'] * 1e-3
+clock = 2.4e9
+simds = 256 * 4
+valu = {
+    "workload": "cfg2, 256 frames, one batch at a time (bench.py --in-flight 1), default scheduling",
+    "source": "profiles/%s_pmc_sq_per_launch.csv (rocprofv3 --pmc, five passes; tools/profile_r2.sh)" % RND,
+    "valu_wave_instructions_per_launch": valu_insts,
+    "sq_active_inst_valu_quad_cycles": active,
+    "refine_stage_s_one_batch_alone": step_s,
+    "valu_busy_frac": active * 4 / (simds * step_s * clock),
+    "valu_issue_bound_s": valu_insts * 4 / simds / clock,
+    "mfma_busy_frac": mfma_busy / (simds * step_s * clock),
+    "note": "valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x refine-stage time x 2.4 GHz); "
+            "valu_issue_bound_s = the time the VALU wave-instructions of one step need at one per 4 cycles "
+            "on every SIMD (f64 FMA issues at half that rate)",
+}
+json.dump(valu, open('profiles/valu_cfg2.json', 'w'), indent=1)
+
+# ---- kernel stats and bench lines ---------------------------------------------------------------------
+shutil.copy(latest('%s/prof/*/*kernel_stats.csv' % SRC), 'profiles/%s_kernel_stats.csv' % RND)
+shutil.copy(latest('%s/prof_inflight1/*/*kernel_stats.csv' % SRC), 'profiles/%s_kernel_stats_inflight1.csv' % RND)
+for fn, o in (('bench', '%s_bench.json' % RND), ('bench_inflight1', '%s_bench_inflight1.json' % RND),
+              ('bench_cfg5', '%s_bench_cfg5.json' % RND)):
+    path = '%s/%s.json' % (SRC, fn)
+    if not os.path.exists(path):
+        continue
+    line = open(path).read().strip().splitlines()[-1]
     open('profiles/' + o, 'w').write(line + '\n')
     d = json.loads(line)
     print(fn, round(d['value'] / 1e6, 3), 'M fits/s', round(d['ms_per_step'], 3), 'ms/step; failed',
           d.get('failed_clusters'), 'in flight', d.get('batches_in_flight'), d.get('in_flight_results_identical'))
 print('refine kernels: FETCH %.0f KB WRITE %.0f KB -> %.1f MB per step' % (f, w, (2 * f + w) * 1024 / 1e6))
+print('VALU busy %.3f, issue bound %.3f ms of %.3f ms' % (valu['valu_busy_frac'], valu['valu_issue_bound_s'] * 1e3, step_s * 1e3))
