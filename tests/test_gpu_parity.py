@@ -28,7 +28,7 @@ def assert_batches_close(b_gpu, b_ref, pos_slice, atol=1e-7):
     rows = np.repeat(ok, np.diff(b_gpu.feat_offset))
     d = np.abs(b_gpu.params_out[:, pos_slice] - b_ref.params_out[:, pos_slice])[rows]
     assert d.max() < atol, d.max()
-    assert_allclose(b_gpu.params_out[rows], b_ref.params_out[rows], rtol=1e-7, atol=1e-7)
+    assert_allclose(b_gpu.params_out[rows], b_ref.params_out[rows], rtol=max(atol, 1e-7), atol=max(atol, 1e-7))
     assert_equal(b_gpu.params_out[~rows], b_gpu.params[~rows])   # failures keep their input
 
 
@@ -44,7 +44,10 @@ def test_golden_case_engine_vs_oracle_and_reference(engine, oracle, name):
     engine.refine_batch(prep.problem, prep.batch)
     oracle.run_batch(prep.problem, ref_batch)
     nd = len(case.pos_columns)
-    assert_batches_close(prep.batch, ref_batch, slice(2, 2 + nd))
+    # (the solver-specific fixtures hold poorly conditioned minima -- the constraint contradicts the
+    #  data, cost > 0.1 -- where the summation order shows at the 1e-7 px level)
+    assert_batches_close(prep.batch, ref_batch, slice(2, 2 + nd),
+                         atol=1e-6 if _cases.is_solver_specific(name) else 1e-7)
     assert_equal(prep.batch.n_rounds, ref_batch.n_rounds)
     res = cta.write_back(prep)
     if case.ref_aborts:
