@@ -593,6 +593,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
   int round = 0, it = 0, iters = 0, Pround = 0;
   double mu = 1e-3, nu = 2., S = 0., pred = 0., rms = NAN;
   bool retr_fail = false;   // the start vector could not be brought onto the constraint manifold
+  double prev_step = INFINITY, trial_step = 0.;   // relative size of the last accepted / of the pending step
   bool last_acc = true;
   double gain = INFINITY;  // relative merit decrease of the last accepted step
   const double fm = k.fmax[k.frame_index[cl]];
@@ -918,7 +919,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         if (P == 0) { status = CTR_STATUS_OUT_OF_BOUNDS; failed = true; }
         else if (!isfinite(St) || retr_fail) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
         // (a size among the variables: more damping at the start, see oracle solve())
-        mu = size_is_var ? 1. : 1e-3; nu = 2.; last_acc = true; gain = INFINITY;
+        mu = size_is_var ? 1. : 1e-3; nu = 2.; last_acc = true; gain = INFINITY; prev_step = INFINITY;
         Pround = P;
         accept = !failed;
       } else if (phase == BP_EVAL_TRIAL) {
@@ -933,6 +934,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           gain = act / (0.5 * S + 1e-300);
           accept = true;
           last_acc = true;
+          prev_step = trial_step;
         } else {
           mu *= nu; nu *= 2.; last_acc = false;
           if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
@@ -1242,6 +1244,17 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             next = BP_STEP_ONLY;
           } else {
             converged = (last_acc && stepmax <= xtol) || fabs(pred) <= tiny;
+            // converging faster than linearly and the step after this one would be below xtol:
+            // finished by TAKING this step, without the pixel pass that would only confirm it
+            // (oracle solve(): fast exit)
+            if (!converged && last_acc && pred > 0. && stepmax < prev_step && isfinite(prev_step) &&
+                stepmax * (stepmax / prev_step) <= xtol) {
+              for (int i = lane; i < nv; i += WAVE) v[i] = vt[i];
+              wsync();
+              S = fmax(S - 2. * pred, 0.);
+              converged = true;
+            }
+            trial_step = stepmax;
             next = BP_EVAL_TRIAL;
             if (!converged && !(pred > 0.)) {
               // the model itself predicts no decrease: rejected without a pixel pass

@@ -199,6 +199,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
   int round = 0, it = 0, iters = 0, Pround = 0;
   double mu = 1e-3, nu = 2., S = 0., pred = 0., rms = NAN, gain = INFINITY;
   bool last_acc = true, bad_size = false;
+  double prev_step = INFINITY, trial_step = 0.;
   const double fm = k.fmax[k.frame_index[cl]];
   const double norm = fm * fm / k.prob.residual_factor;  // refine.py:354
   const double ms2 = k.prob.max_shift * k.prob.max_shift;
@@ -645,6 +646,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
     fill_fpar(vt, size_is_var || round == 0);
     it = 0;
     mu = size_is_var ? 1. : 1e-3; nu = 2.; last_acc = true; gain = INFINITY;   // (oracle solve())
+    prev_step = INFINITY;
 
     // ---- one solver run ------------------------------------------------------------------
     bool need_eval = true, first = true, converged = false, failed = false;
@@ -675,6 +677,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
             gain = act / (0.5 * S + 1e-300);
             accept = true;
             last_acc = true;
+            prev_step = trial_step;
           } else {
             mu *= nu; nu *= 2.; last_acc = false;
             if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
@@ -949,6 +952,16 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         continue;
       }
       if ((last_acc && stepmax <= xtol) || fabs(pred) <= tiny) { converged = true; break; }
+      if (last_acc && pred > 0. && stepmax < prev_step && isfinite(prev_step) &&
+          stepmax * (stepmax / prev_step) <= xtol) {
+        // (oracle solve(): fast exit -- the step is taken, the confirming pixel pass skipped)
+        for (int i = tid; i < nv; i += LT) v[i] = vt[i];
+        __syncthreads();
+        S = fmax(S - 2. * pred, 0.);
+        converged = true;
+        break;
+      }
+      trial_step = stepmax;
       if (!(pred > 0.)) {
         // the model itself predicts no decrease: rejected without a pixel pass
         mu *= nu; nu *= 2.; last_acc = false;

@@ -80,6 +80,7 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
   double mco[NF][ND], isz2[NF][ND];  // mask centres, 1/size^2 (p0 rows are re-read from HBM when needed)
   double mu = 1e-3, nu = 2., S = 0., pred = 0., norm = 1., rms = NAN;
   bool last_acc = true, bad_size = false;
+  double prev_step = INFINITY, trial_step = 0.;  // relative size of the last accepted / of the pending step
   double gain = INFINITY;  // relative decrease of S by the last accepted step
   const char* frame = nullptr;
 
@@ -305,7 +306,7 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
       if (phase == PH_EVAL_INIT) {
         if (P == 0) { status = CTR_STATUS_OUT_OF_BOUNDS; failed = true; }
         else if (!isfinite(St) || bad_size) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
-        mu = 1e-3; nu = 2.; last_acc = true; gain = INFINITY;
+        mu = 1e-3; nu = 2.; last_acc = true; gain = INFINITY; prev_step = INFINITY;
         Pround = P;
       }
       bool accept = phase == PH_EVAL_INIT;
@@ -319,6 +320,7 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
           gain = act / (0.5 * S + 1e-300);
           accept = true;
           last_acc = true;
+          prev_step = trial_step;
         } else {
           mu *= nu; nu *= 2.; last_acc = false;
           if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
@@ -480,6 +482,17 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
             phase = PH_STEP_ONLY;
           } else {
             converged = (last_acc && stepmax <= xtol) || fabs(pred) <= tiny;
+            // converging faster than linearly and the step after this one would be below xtol:
+            // finished by TAKING this step, without the pixel pass that would only confirm it
+            // (oracle solve(): fast exit)
+            if (!converged && last_acc && pred > 0. && stepmax < prev_step && isfinite(prev_step) &&
+                stepmax * (stepmax / prev_step) <= xtol) {
+#pragma unroll
+              for (int j = 0; j < NV; ++j) v[j] = vt[j];
+              S = fmax(S - 2. * pred, 0.);
+              converged = true;
+            }
+            trial_step = stepmax;
             phase = PH_EVAL_TRIAL;
             if (!converged && !(pred > 0.)) {
               // the model itself predicts no decrease: rejected without a pixel pass

@@ -145,12 +145,10 @@ def draw_frames(shape, frame_of, pos, size, max_value, n_frames=None, noise=0., 
                                                       t_size.data_ptr(), t_mv.data_ptr())
         sy.noise = float(noise)
         sy.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-        cur = torch.cuda.current_stream(dev)
-        if cur.cuda_stream != 0:
-            eng.draw_frames_device(sy, out.data_ptr(), cur.cuda_stream)
-            cur.synchronize()            # the inputs above must outlive the kernels
-        else:
-            eng.engine_wait_stream(0)
-            eng.draw_frames_device(sy, out.data_ptr(), 0)
-            eng.synchronize()
+        # the uploads above go through torch's stream (pageable host memory: staged copies); the
+        # kernels run on the engine's own stream: a host-side synchronisation on both sides of
+        # the call orders them whatever streams are current (this is a generator, not a hot path)
+        torch.cuda.synchronize(dev)
+        eng.draw_frames_device(sy, out.data_ptr(), 0)
+        eng.synchronize()
     return out

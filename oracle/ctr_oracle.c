@@ -435,6 +435,8 @@ static int use_newton = 1;
 void ctro_set_newton(int on) { use_newton = on; }
 /* diagnostic switch: print one line per solver iteration to stderr */
 static int trace = 0;
+static int fast_exit = 1;
+void ctro_set_fast_exit(int on) { fast_exit = on; }
 static double mu0_sizevar = 1.;
 void ctro_set_mu0_sizevar(double x) { mu0_sizevar = x; }
 void ctro_set_trace(int on) { trace = on; }
@@ -548,6 +550,7 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
   double S, St, mu, nu = 2.;
   long P;
   int last_accepted = 1, it = 0;
+  double prev_step = INFINITY; /* relative size of the last accepted step */
   double gain = INFINITY; /* relative decrease of the objective by the last accepted step */
 
   for (int i = 0; i < nv; ++i) {
@@ -713,6 +716,18 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
       out.ok = 1;
       break;
     }
+    /* Converging faster than linearly at rate r = step / previous step: the step after this
+     * one would be <= r * step.  Where that is below xtol the fit is finished by TAKING this
+     * step, without the pixel pass that would only confirm it (the point returned is then as
+     * exact as the one the plain test returns an iteration later; S from the model). */
+    if (fast_exit && last_accepted && pred > 0. && stepmax < prev_step && isfinite(prev_step) &&
+        stepmax * (stepmax / prev_step) <= xtol) {
+      memcpy(v, vt, sizeof(double) * nv);
+      S -= 2. * pred;
+      if (S < 0.) S = 0.;
+      out.ok = 1;
+      break;
+    }
     if (trace > 2 && !(pred > 0.)) fprintf(stderr, "   it %d: pred %g, no trial\n", it, pred);
     if (!(pred > 0.)) {
       /* the model itself predicts no decrease (projection): rejected without looking at the
@@ -750,6 +765,7 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
       memcpy(Cj, Cjt, sizeof(double) * (size_t)(m ? m : 0) * nv);
       S = St;
       last_accepted = 1;
+      prev_step = stepmax;
     } else {
       mu *= nu;
       nu *= 2.;
