@@ -46,7 +46,7 @@ with open('profiles/%s_pmc_per_launch.csv' % RND, 'w') as fo:
 def step_total(counter):
     # kernels of one step with the bench's scheduling: the 8-wave block kernels only run in
     # the five "one batch alone" launches at the end
-    skip = ('refine_block_kernel<2, true, 1, 8>', 'refine_block_kernel<2, true, 2, 8>')
+    skip = ('refine_block_kernel<2, true, 1, 8', 'refine_block_kernel<2, true, 2, 8')
     return sum(sum(v) / len(v) for k, v in tot[counter].items()
                if ('refine_' in k or 'front_load' in k) and not any(x in k for x in skip))
 
