@@ -39,8 +39,10 @@ enum { PH_FETCH = 0, PH_EVAL_INIT = 1, PH_EVAL_TRIAL = 2, PH_STEP_ONLY = 3, PH_D
 
 // SG = lanes per cluster: 8 (eight singles per wave), 16 (four pairs per wave) or 64 (pairs: a
 // quarter of the per-iteration latency, which is what bounds the slowest pair).
+// (singles: at least 3 waves per SIMD = at most 168 VGPRs; measured best of 128 / 168 / 203+ with
+//  two pixels per lane in flight, tools/ab_classes.py: 0.375 -> 0.305 ms for the 33 k singles of cfg 2)
 template <int ND, int NF, bool ISO, int SG>
-__global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* __restrict__ counter) {
+__global__ void __launch_bounds__(WAVE, NF == 1 ? 3 : 1) refine_small_kernel(const KArgs k, int* __restrict__ counter) {
   constexpr int NV = 1 + NF * (1 + ND);
   constexpr int NR = NV + 1;               // row length incl. the residual
   constexpr int NM = NR * (NR + 1) / 2;    // packed upper triangle
@@ -212,6 +214,87 @@ __global__ void __launch_bounds__(WAVE) refine_small_kernel(const KArgs k, int* 
       const float inv_w1 = ND == 3 ? 1.f / (float)wshape[1] : 1.f;
       const bool big_window = npix >= (1 << 21);
       const double bg = vt[0];
+      if constexpr (NF == 1) {
+#ifndef CTR_SMALL_PX
+#define CTR_SMALL_PX 2
+#endif
+        constexpr int PX = CTR_SMALL_PX;
+        // Singles (the bulk of a frame): PX pixels per lane in flight and no branch around
+        // the model -- the chains of dependent f64 operations of the two pixels interleave
+        // (the kernel is latency bound at 4 waves per SIMD); a lane outside the window or the
+        // mask contributes a zero row.  Same sums as the loop below, other order.
+        for (int base = 0; __any(base < npix_here); base += PX * SG) {
+          double rw[PX][NR], Ek[PX][ND];
+#pragma unroll
+          for (int u = 0; u < PX; ++u) {
+            const int q = base + u * SG + sub;
+            const bool valid = q < npix_here;
+            int idx[ND];
+            size_t off;
+            {
+              const int t = big_window ? q / w_last : (int)(((float)q + 0.5f) * inv_w2);
+              const int x = q - t * w_last;
+              if (ND == 3) {
+                const int z = big_window ? t / wshape[1] : (int)(((float)t + 0.5f) * inv_w1);
+                const int y = t - z * wshape[1];
+                idx[0] = z; idx[1] = y; idx[ND - 1] = x;
+                off = ((size_t)(z + origin[0]) * fshape[1] + (y + origin[1])) * fshape[ND - 1] + (x + origin[ND - 1]);
+              } else {
+                idx[0] = t; idx[ND - 1] = x;
+                off = (size_t)(t + origin[0]) * fshape[ND - 1] + (x + origin[ND - 1]);
+              }
+            }
+            const double pix = valid ? load_pixel(frame, k.frame_dtype, off) : 0.;
+            double rel[ND];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) rel[a] = mco[0][a] - (double)origin[a];
+            const bool in = valid && in_mask<ND>(idx, rel, inv_r2, radius);
+            double r2 = 0., dd[ND];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              dd[a] = (double)(idx[a] + origin[a]) - vt[2 + a];
+              r2 += dd[a] * dd[a] * isz2[0][a];
+            }
+            const double gv = exp(-0.5 * ND * r2);
+            const double sig = vt[1];
+            const double res = (pix - bg) - sig * gv;
+            const bool ok = in && (res == res);
+            P += in ? 1 : 0;
+            const double sng = -sig * (double)ND * gv;
+            rw[u][0] = ok ? -1. : 0.;
+            rw[u][1] = ok ? -gv : 0.;
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              const double t = dd[a] * isz2[0][a];
+              rw[u][2 + a] = ok ? sng * t : 0.;
+              Ek[u][a] = ok ? (double)ND * t : 0.;
+            }
+            rw[u][NV] = ok ? res : 0.;
+          }
+          int e = 0;
+#pragma unroll
+          for (int p = 0; p < NR; ++p)
+#pragma unroll
+            for (int c2 = p; c2 < NR; ++c2) {
+              double t = rw[0][p] * rw[0][c2];
+#pragma unroll
+              for (int u = 1; u < PX; ++u) t += rw[u][p] * rw[u][c2];
+              M[e] += t;
+              ++e;
+            }
+#pragma unroll
+          for (int a = 0; a < ND; ++a) {
+#pragma unroll
+            for (int b = a; b < ND; ++b) {
+              double t = 0.;
+#pragma unroll
+              for (int u = 0; u < PX; ++u) t += (rw[u][NV] * rw[u][2 + a]) * Ek[u][b];
+              M[e] += t;
+              ++e;
+            }
+          }
+        }
+      } else
       for (int base = 0; __any(base < npix_here); base += SG) {
         const int q = base + sub;
         if (q < npix_here) {
