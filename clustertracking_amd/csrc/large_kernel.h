@@ -21,7 +21,8 @@
 #ifndef CTREFINE_LARGE_KERNEL_H
 #define CTREFINE_LARGE_KERNEL_H
 
-constexpr int LW = 16;             // wavefronts per workgroup
+constexpr int LW = 8;              // wavefronts per workgroup (512 threads: 256 VGPRs per lane -- with 1024
+                                   // the kernel spilled 0.8-1.3 KB per lane; two workgroups fit a CU's LDS)
 constexpr int LT = LW * WAVE;      // threads
 constexpr int LRS = 17;            // row stride of a wave's LDS tile (odd: conflict-free ds_write_b64)
 constexpr int LRED = 12;           // values per wave in the reduction scratch
@@ -253,7 +254,27 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       }
       const int cnt = nbcnt[i];
       const int* nb = nbidx + (size_t)i * LARGE_MAXNB;
-      const double* fi = fpar + (size_t)i * FP;
+      // This feature's constants in registers; neighbour l's (index, mask centre relative to the
+      // window, derived constants) in the registers of LANE l, broadcast with v_readlane when a
+      // tile needs them: read from the workspace once per feature, not once per tile and
+      // neighbour (dependent L2 round trips made a tile cost 14 us).
+      double fi[13];
+#pragma unroll
+      for (int q2 = 0; q2 < 13; ++q2) fi[q2] = fpar[(size_t)i * FP + q2];
+      int nj = 0;
+      double nrel[ND], nf[13];
+#pragma unroll
+      for (int a = 0; a < ND; ++a) nrel[a] = 0.;
+#pragma unroll
+      for (int q2 = 0; q2 < 13; ++q2) nf[q2] = 0.;
+      if (lane < cnt) {
+        nj = nb[lane];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) nrel[a] = mco[nj * 3 + a] - (double)origin[a];
+#pragma unroll
+        for (int q2 = 0; q2 < 13; ++q2) nf[q2] = fpar[(size_t)nj * FP + q2];
+      }
+      const unsigned long long tf0 = __builtin_amdgcn_s_memrealtime();
       v4d acc = v4d{0., 0., 0., 0.};
       constexpr int NUF = ND * (ND + 1) / 2;
       double uacc[NUF];
@@ -265,6 +286,33 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         int idx[ND];
         bool in_i = false;
         size_t offp = 0;
+        // Which neighbours can touch this tile at all?  Lane l tests the box of neighbour l
+        // (centre +- radius, a superset of its mask) against the index extent of the 64
+        // consecutive box pixels: one ballot gives the candidates (as in block_kernel.h).
+        unsigned long long cand;
+        {
+          const int q0 = base, q1 = base + WAVE - 1 < npx ? base + WAVE - 1 : npx - 1;
+          int lo_i[ND], hi_i[ND];
+          int t0 = q0, t1 = q1;
+          bool same = true;   // all slower axes equal so far
+          int c0[ND], c1[ND];
+#pragma unroll
+          for (int a = ND - 1; a >= 0; --a) {
+            c0[a] = t0 % bsz[a]; t0 /= bsz[a];
+            c1[a] = t1 % bsz[a]; t1 /= bsz[a];
+          }
+#pragma unroll
+          for (int a = 0; a < ND; ++a) {
+            lo_i[a] = blo[a] + (same ? c0[a] : 0);
+            hi_i[a] = blo[a] + (same ? c1[a] : bsz[a] - 1);
+            same = same && c0[a] == c1[a];
+          }
+          bool hit = lane < cnt;
+#pragma unroll
+          for (int a = 0; a < ND; ++a)
+            hit = hit && ((double)hi_i[a] >= nrel[a] - (double)radius[a]) && ((double)lo_i[a] <= nrel[a] + (double)radius[a]);
+          cand = __ballot(hit);
+        }
         if (q < npx) {
           int t = q;
 #pragma unroll
@@ -285,8 +333,10 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         }
 #pragma unroll
         for (int c2 = 0; c2 < 16; ++c2) row[c2] = 0.;
-        if (in_i) {
-          const double pix = load_pixel(frame, k.frame_dtype, offp);
+        {
+          // (all lanes run the neighbour loop -- v_readlane must not sit in divergent control
+          //  flow: a spilled source register is reloaded for the active lanes only)
+          const double pix = in_i ? load_pixel(frame, k.frame_dtype, offp) : 0.;
           double res = pix - bgv;
           bool owner = true;
           double shared[CTR_MAX_PARAMS], down[1 + ND + NSZ];
@@ -297,17 +347,26 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
           double Eown[ND];
 #pragma unroll
           for (int a = 0; a < ND; ++a) Eown[a] = 0.;
-          // the features that cover this pixel: i itself and its neighbours (ascending order)
-          for (int s2 = -1; s2 < cnt; ++s2) {
-            const int j = s2 < 0 ? i : nb[s2];
-            const double* f = s2 < 0 ? fi : fpar + (size_t)j * FP;
-            if (s2 >= 0) {
+          // the features that cover this pixel: i itself and the tile's candidate neighbours
+          // (ascending order)
+          unsigned long long todo = cand;
+          for (int s2 = -1;;) {
+            double f[13];
+            bool covered = in_i;
+            if (s2 < 0) {
+#pragma unroll
+              for (int q2 = 0; q2 < 13; ++q2) f[q2] = fi[q2];
+            } else {
               double rel[ND];
 #pragma unroll
-              for (int a = 0; a < ND; ++a) rel[a] = mco[j * 3 + a] - (double)origin[a];
-              if (!in_mask<ND>(idx, rel, inv_r2, radius)) continue;
-              if (j < i) owner = false;
+              for (int a = 0; a < ND; ++a) rel[a] = readlane_f64(nrel[a], s2);
+              covered = in_i && in_mask<ND>(idx, rel, inv_r2, radius);
+              const int j = __builtin_amdgcn_readlane(nj, s2);
+              if (covered && j < i) owner = false;
+#pragma unroll
+              for (int q2 = 0; q2 < 13; ++q2) f[q2] = readlane_f64(nf[q2], s2);
             }
+            if (covered) {
             double r2 = 0., dd[ND], d[1 + ND + NSZ];
 #pragma unroll
             for (int a = 0; a < ND; ++a) {
@@ -335,9 +394,14 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
 #pragma unroll
               for (int a = 0; a < ND; ++a) Eown[a] = (double)ND * (dd[a] * f[4 + a]);
             }
+            }
+            // next candidate
+            if (todo == 0ull) break;
+            s2 = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
           }
-          Pown += owner ? 1 : 0;
-          if (res == res) {   // nansum (fitfunc.py:449,483): a NaN pixel counts in P only
+          Pown += (in_i && owner) ? 1 : 0;
+          if (in_i && res == res) {   // nansum (fitfunc.py:449,483): a NaN pixel counts in P only
             const double ow = owner ? 1. : 0.;
             row[0] = res;
             row[c_reso] = ow * res;
@@ -383,16 +447,19 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
           if (lane == 0) uq[(size_t)i * 16 + LQT + t] = s;   // raw sums of the TRIAL point (tabulated on accept)
         }
       }
+      const unsigned long long tf1 = __builtin_amdgcn_s_memrealtime();
       // ---- neighbour blocks: d_i d_j^T over mask i & mask j, for the neighbours j > i -------
       for (int s2 = 0; s2 < cnt; ++s2) {
-        const int j = nb[s2];
+        const int j = __builtin_amdgcn_readlane(nj, s2);
         if (j < i) continue;
-        const double* fj = fpar + (size_t)j * FP;
+        double fj[13];
+#pragma unroll
+        for (int q2 = 0; q2 < 13; ++q2) fj[q2] = readlane_f64(nf[q2], s2);
         double rel_j[ND];
         int plo[ND], psz[ND], np2 = 1;
 #pragma unroll
         for (int a = 0; a < ND; ++a) {
-          rel_j[a] = mco[j * 3 + a] - (double)origin[a];
+          rel_j[a] = readlane_f64(nrel[a], s2);
           int l = (int)ceil(rel_j[a] - (double)radius[a]), u = (int)floor(rel_j[a] + (double)radius[a]);
           l = l < blo[a] ? blo[a] : l;
           u = u > blo[a] + bsz[a] - 1 ? blo[a] + bsz[a] - 1 : u;
@@ -432,7 +499,9 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
             if (pix == pix) {   // (a NaN pixel of the image contributes nothing)
 #pragma unroll
               for (int side = 0; side < 2; ++side) {
-                const double* f = side == 0 ? fi : fj;
+                double f[13];
+#pragma unroll
+                for (int q2 = 0; q2 < 13; ++q2) f[q2] = side == 0 ? fi[q2] : fj[q2];
                 double r2 = 0., dd[ND], d[1 + ND + NSZ];
 #pragma unroll
                 for (int a = 0; a < ND; ++a) {
@@ -481,6 +550,10 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
             }
           }
         }
+      }
+      if (tid == 0) {
+        atomicAdd(&g_large_dbg[6], tf1 - tf0);
+        atomicAdd(&g_large_dbg[7], __builtin_amdgcn_s_memrealtime() - tf1);
       }
     }
     // sums over the features of every tile entry: the "_o" entries are the cluster totals
@@ -890,11 +963,13 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         for (int i = tid; i < nv; i += LT) ps[i] = zs[i];
         const double rz0 = rz[0];
         bool cg_fail = !(rz0 >= 0.) || !isfinite(rz0);
-        // to a relative residual of 1e-11 in the preconditioned norm (the step of an LM iteration
-        // need not be more exact; the convergence test looks at steps of 1e-9 relative size)
+        // Inexact steps while the iteration is far from the minimum (relative residual 1e-6 in
+        // the preconditioned norm), 1e-11 once the accepted steps are small: the convergence
+        // test looks at steps of 1e-9 relative size, and the fast exit at their ratio.
+        const double cg_tol2 = (last_acc && prev_step < 1e-4) ? 1e-22 : 1e-12;
         const int cg_max = nv < 400 ? nv + 20 : 420;
         int cg_it = 0;
-        for (int ci = 0; ci < cg_max && !cg_fail && rz[0] > 1e-22 * rz0 && rz[0] > 0.; ++ci) {
+        for (int ci = 0; ci < cg_max && !cg_fail && rz[0] > cg_tol2 * rz0 && rz[0] > 0.; ++ci) {
           ++cg_it;
           const double pAp = matvec(ps, Aps, tl, ol, mu, nwt, fre);
           if (!(pAp > 0.) || !isfinite(pAp)) { cg_fail = true; break; }   // not positive definite

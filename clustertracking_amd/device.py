@@ -113,9 +113,9 @@ def draw_frames(shape, frame_of, pos, size, max_value, n_frames=None, noise=0., 
     ndim = len(shape)
     pos = np.ascontiguousarray(np.asarray(pos, dtype=np.float64).reshape(-1, ndim))
     n = len(pos)
-    frame_of = np.array(np.broadcast_to(np.asarray(frame_of, dtype=np.int32), (n,)))
-    size = np.array(np.broadcast_to(np.asarray(size, dtype=np.float64), (n, ndim)))
-    max_value = np.array(np.broadcast_to(np.asarray(max_value, dtype=np.float64), (n,)))
+    frame_of = np.array(np.broadcast_to(np.asarray(frame_of, dtype=np.int32), (n,)), order='C')
+    size = np.array(np.broadcast_to(np.asarray(size, dtype=np.float64), (n, ndim)), order='C')
+    max_value = np.array(np.broadcast_to(np.asarray(max_value, dtype=np.float64), (n,)), order='C')
     if n_frames is None:
         n_frames = int(frame_of.max()) + 1 if n else 0
     if n and (frame_of.min() < 0 or frame_of.max() >= n_frames):
