@@ -54,6 +54,10 @@ def parse():
                     help="cfg2: draw the frames ON THE DEVICE from the seeds' truth positions "
                          "(ctr_draw_frames_device; the Poisson noise is then the engine's own generator, "
                          "not NumPy's: same statistics, other bytes)")
+    ap.add_argument('--gather', default='step', choices=['step', 'final'],
+                    help="N > 1: gather the result rows of EVERY step on rank 0 (default; issued from the "
+                         "host as steps finish, ctr_query_done, so that no stream sits in a device-side "
+                         "wait) or only those of the last step")
     ap.add_argument('--single-device', action='store_true',
                     help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
@@ -181,7 +185,14 @@ def main():
     if nfl > 1:     # several batches in flight: machine time per cluster before one-batch latency
         prep.problem.flags |= _abi.FLAG_THROUGHPUT
     engines = [_lib.default_engine(local_rank)] + [_lib.Engine(local_rank) for _ in range(nfl - 1)]
-    dbs = [DeviceBatch(prep.problem, prep.batch, device=local_rank, engine=e) for e in engines]
+    pad_rows = 0
+    if multi and args.gather == 'step':
+        # every rank sends the same number of rows: the largest feature count of any rank
+        cnt_t = [torch.zeros(1, dtype=torch.int64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(cnt_t, torch.tensor([prep.batch.n_features], dtype=torch.int64, device=coll_dev))
+        pad_rows = max(int(c.item()) for c in cnt_t)
+    dbs = [DeviceBatch(prep.problem, prep.batch, device=local_rank, engine=e, result_rows=pad_rows)
+           for e in engines]
     db = dbs[0]
     n_fits = prep.batch.n_clusters
     n_feat = prep.batch.n_features
@@ -190,14 +201,19 @@ def main():
     # engines; an engine's own stream keeps its steps in order, different engines overlap
     # on the GPU, so the slowest clusters of one step (a bin lasts as long as its slowest
     # cluster) no longer hold up the next steps.
-    # The only exchange of the path (north_star: RCCL only for the final gather): when the K
-    # steps of the job are done, the result rows of every rank go to rank 0 -- one gather,
-    # inside the timed region.  (A gather per step was tried: with batches in flight every
-    # stream that sits in a device-side wait for a slow step blocks the streams sharing its
-    # hardware queue, and issuing the gathers from the host in step order stalls the host
-    # behind the slowest step; 15-30 % of the throughput either way.)
+    # The only exchange of the path (north_star: RCCL only for the result gather): the result
+    # rows of every step go from every rank to rank 0, inside the timed region.  With batches in
+    # flight a gather must not park a stream in a device-side wait for a slow step (it blocks the
+    # streams sharing its hardware queue) nor stall the host behind the slowest step (round 1:
+    # 15-30 % of the throughput either way).  So the HOST hands finished steps on: after every
+    # launch it asks, without blocking, which of the oldest steps in flight have finished
+    # (ctr_query_done), packs their rows into that slot's send buffer and issues the gather
+    # asynchronously; a slot is only waited for when its turn comes again before its step has
+    # been handed on.  --gather final: the rows of the last step only (round 1's protocol).
     step_no = [0]
     send, gather_buf = None, None
+    pending = []          # slots whose step has been launched and not yet gathered, oldest first
+    slot_work = [None] * max(1, args.in_flight)   # the asynchronous gather that last used a slot's buffers
     if multi:
         counts = [torch.zeros(1, dtype=torch.int64, device=coll_dev) for _ in range(world)]
         dist.all_gather(counts, torch.tensor([n_feat], dtype=torch.int64, device=coll_dev))
@@ -208,14 +224,56 @@ def main():
         if rank == 0:
             gather_buf = [torch.empty((pad, width), dtype=torch.float64, device=coll_dev)
                           for _ in range(world)]
+            gather_bufs = [[torch.empty((pad, width), dtype=torch.float64, device=coll_dev)
+                            for _ in range(world)] for _ in range(nfl)]
         # cluster of every feature row, resident on the device: cost[row_cluster] = cost per row
         row_cluster = torch.from_numpy(np.repeat(np.arange(n_fits, dtype=np.int64),
                                                  np.diff(prep.batch.feat_offset))).to(db.device)
 
+    def hand_on(slot):
+        """pack the rows of the finished step of `slot` and issue their gather (asynchronous)"""
+        d = dbs[slot]
+        # the engine has written the rows of the result table (params | cost of the row's
+        # cluster, ctr_batch.result_rows) into the slot's send block itself: nothing to pack
+        buf = d.t['result_rows'] if coll_dev == 'cuda' else d.t['result_rows'].cpu()
+        slot_work[slot] = dist.gather(buf, gather_bufs[slot] if rank == 0 else None, dst=0, async_op=True)
+
+    def poll(block_slot=None):
+        """hand on the oldest finished steps; with block_slot, everything up to that slot"""
+        while pending:
+            slot = pending[0]
+            if not dbs[slot].engine.query_done():
+                if block_slot is None:
+                    return
+                dbs[slot].engine.synchronize()
+            pending.pop(0)
+            hand_on(slot)
+            if slot == block_slot:
+                block_slot = None
+
+    per_step_gather = multi and args.gather == 'step'
+
     def step():
-        d = dbs[step_no[0] % nfl]
+        slot = step_no[0] % nfl
+        d = dbs[slot]
         step_no[0] += 1
+        if per_step_gather:
+            if slot in pending:
+                poll(block_slot=slot)                   # its previous step has not been handed on yet
+            if slot_work[slot] is not None:
+                slot_work[slot].wait()                  # the gather that reads its send block (long done)
+                d.engine.engine_wait_stream(0)
         d.engine.refine_batch_device(d.plan, d.struct, 0)   # the engine's own stream
+        if per_step_gather:
+            pending.append(slot)
+            poll()
+
+    def flush_gathers():
+        if pending:
+            poll(block_slot=pending[-1])
+        for w in slot_work:
+            if w is not None:
+                w.wait()
 
     def final_gather():
         d = dbs[(step_no[0] - 1) % nfl]                 # the batch of the last step
@@ -241,13 +299,16 @@ def main():
     for _ in range(args.warmup):
         step()
     if multi:
+        flush_gathers()
         final_gather()      # (the first gather sets up the point-to-point channels)
     fence()
     fm_ms, rf_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if multi:
+    if per_step_gather:
+        flush_gathers()
+    elif multi:
         final_gather()
     fence()
     elapsed = time.perf_counter() - t0
@@ -272,10 +333,11 @@ def main():
     if multi and rank == 0:
         # what arrived in the last gather: rank 0's own rows must be its results, every other
         # rank's rows finite positions inside its frames
-        own = gather_buf[0][:n_feat, :width - 1].to(db.device)
+        last = gather_bufs[(step_no[0] - 1) % nfl] if per_step_gather else gather_buf
+        own = last[0][:n_feat, :width - 1].to(db.device)
         gather_ok = bool(torch.equal(own, db.t['params_out']))
         for r in range(1, world):
-            rows = gather_buf[r][:counts[r], 2:4]
+            rows = last[r][:counts[r], 2:4]
             gather_ok = gather_ok and bool(torch.isfinite(rows).all()) and bool((rows > -20).all())
 
     t_all = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
@@ -354,6 +416,7 @@ def main():
             "host_prepare_s": t_host_prep,
             **extra_info,
             "gather_checked": gather_ok,
+            "gather": (args.gather if multi else None),
             "batches_in_flight": nfl,
             "in_flight_results_identical": copies_same,
         }

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_NDIM = 3
 MAX_PARAMS = 8
 MAX_VARS = 127
@@ -62,6 +62,7 @@ class Batch(C.Structure):
         ('params', C.c_void_p), ('low', C.c_void_p), ('high', C.c_void_p),
         ('params_out', C.c_void_p), ('cost', C.c_void_p), ('status', C.c_void_p),
         ('n_rounds', C.c_void_p), ('n_iter', C.c_void_p), ('params_std', C.c_void_p),
+        ('result_rows', C.c_void_p),
     ]
 
 

@@ -18,7 +18,7 @@ EXPORTS = ('ctr_abi_version', 'ctr_create', 'ctr_destroy', 'ctr_last_error',
            'ctr_plan_create', 'ctr_plan_destroy', 'ctr_refine_batch_device',
            'ctr_frame_max_device', 'ctr_synchronize', 'ctr_last_kernel_ms',
            'ctr_find_clusters', 'ctr_engine_wait_stream', 'ctr_stream_wait_engine',
-           'ctr_draw_frames_device')
+           'ctr_draw_frames_device', 'ctr_query_done')
 
 _lib = None
 _lock = threading.Lock()
@@ -104,6 +104,8 @@ def load():
                 getattr(lib, name).restype = C.c_int
         lib.ctr_draw_frames_device.argtypes = [C.c_void_p, P(_abi.Synth), C.c_void_p, C.c_void_p]
         lib.ctr_draw_frames_device.restype = C.c_int
+        lib.ctr_query_done.argtypes = [C.c_void_p]
+        lib.ctr_query_done.restype = C.c_int
         lib.ctr_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_double), P(C.c_double)]
         lib.ctr_last_kernel_ms.restype = C.c_int
         if lib.ctr_abi_version() != _abi.ABI_VERSION:
@@ -191,6 +193,14 @@ class Engine(object):
         """``ctr_draw_frames_device``: ``synth`` is an ``_abi.Synth`` with device pointers."""
         self._check(self._lib.ctr_draw_frames_device(self._h, C.byref(synth), C.c_void_p(frames_ptr),
                                                      C.c_void_p(stream or 0)), 'ctr_draw_frames_device')
+
+    def query_done(self):
+        """True when the last ``refine_batch_device`` call of this engine has finished on the
+        device (``ctr_query_done``; never blocks)."""
+        rc = self._lib.ctr_query_done(self._h)
+        if rc < 0:
+            raise EngineError("ctr_query_done failed: %s" % (self._lib.ctr_last_error(self._h) or b'').decode())
+        return rc == 1
 
     def synchronize(self, stream=None):
         self._check(self._lib.ctr_synchronize(self._h, C.c_void_p(stream or 0)),

@@ -74,6 +74,21 @@ __global__ void delay_kernel(unsigned long long ticks) {
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
+// ctr_batch.result_rows: [N, n_params + 1] = params_out and the cost of the row's cluster
+__global__ void result_rows_kernel(const double* __restrict__ params_out, const double* __restrict__ cost,
+                                   const int32_t* __restrict__ feat_offset, int n_clusters, int n_features,
+                                   int np, double* __restrict__ rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_features) return;
+  int lo = 0, hi = n_clusters;   // the cluster c with feat_offset[c] <= i < feat_offset[c + 1]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (feat_offset[mid] <= i) lo = mid; else hi = mid;
+  }
+  for (int q = 0; q < np; ++q) rows[(size_t)i * (np + 1) + q] = params_out[(size_t)i * np + q];
+  rows[(size_t)i * (np + 1) + np] = cost[lo];
+}
+
 // clusters the engine cannot take (too many variables / features)
 __global__ void mark_kernel(const KArgs k, int code) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;

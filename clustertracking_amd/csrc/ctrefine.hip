@@ -586,6 +586,10 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
       HIP_TRY(h, hipEventRecord(h->ev_join[j], h->side[j]));
       HIP_TRY(h, hipStreamWaitEvent(s, h->ev_join[j], 0));
     }
+  if (b->result_rows != nullptr && b->n_features > 0)
+    hipLaunchKernelGGL(result_rows_kernel, dim3((unsigned)((b->n_features + 255) / 256)), dim3(256), 0, s,
+                       b->params_out, b->cost, b->feat_offset, (int)b->n_clusters, (int)b->n_features,
+                       (int)p.n_params, b->result_rows);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipEventRecord(h->ev[2], s));
   HIP_TRY(h, hipEventRecord(h->ev_done, s));
@@ -698,6 +702,16 @@ int ctr_synchronize(ctr_handle* h, void* hip_stream) {
   return CTR_OK;
 }
 
+int ctr_query_done(ctr_handle* h) {
+  if (!h) return -1;
+  if (hipSetDevice(h->device) != hipSuccess) return -1;
+  const hipError_t e = hipEventQuery(h->ev_done);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) return 0;
+  h->err = std::string("hipEventQuery: ") + hipGetErrorString(e);
+  return -1;
+}
+
 int ctr_engine_wait_stream(ctr_handle* h, void* hip_stream) {
   if (!h) return CTR_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
@@ -789,6 +803,7 @@ int ctr_refine_batch(ctr_handle* h, const ctr_problem* p, const ctr_batch* b) {
   d.params = d_par; d.low = d_low; d.high = d_high; d.params_out = d_out;
   d.cost = d_cost; d.status = d_status; d.n_rounds = d_rounds; d.n_iter = d_iter;
   d.params_std = d_std;
+  d.result_rows = nullptr;   // (the host-buffer call returns the tables themselves)
   ctr_plan* plan = nullptr;
   rc = ctr_plan_create(h, p, C, b->feat_offset, &plan);
   if (rc) return rc;

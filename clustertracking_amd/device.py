@@ -9,7 +9,11 @@ from . import _abi, _lib
 class DeviceBatch(object):
     """A HostBatch uploaded once; ``run()`` queues one pass of the hot path."""
 
-    def __init__(self, problem, host_batch, device=0, engine=None):
+    def __init__(self, problem, host_batch, device=0, engine=None, result_rows=0):
+        """result_rows: > 0 allocates ``t['result_rows']`` with that many rows (>= the features
+        of the batch; rows beyond them stay zero) of n_params + 1 columns and has the engine write
+        params_out | cost-of-the-row's-cluster into it (``ctr_batch.result_rows``): the block a
+        multi-GPU pipeline gathers, padded to the same row count on every rank."""
         import torch
         self.torch = torch
         self.device = torch.device('cuda', device)
@@ -40,6 +44,12 @@ class DeviceBatch(object):
         if hb.params_std is not None:
             with torch.cuda.device(self.device):
                 self.t['params_std'] = torch.empty(hb.params.shape, dtype=torch.float64, device=self.device)
+        if result_rows:
+            if result_rows < hb.n_features:
+                raise ValueError("result_rows must hold every feature of the batch")
+            with torch.cuda.device(self.device):
+                self.t['result_rows'] = torch.zeros((int(result_rows), hb.params.shape[1] + 1),
+                                                    dtype=torch.float64, device=self.device)
         b = hb.as_struct()
         for name, tensor in self.t.items():
             setattr(b, name, tensor.data_ptr())

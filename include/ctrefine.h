@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CTR_ABI_VERSION 2
+#define CTR_ABI_VERSION 3
 #define CTR_MAX_NDIM 3
 #define CTR_MAX_PARAMS 8 /* background, signal, <=3 positions, <=3 sizes */
 #define CTR_MAX_VARS 127 /* optimiser variables per cluster of the on-chip kernels; larger clusters
@@ -137,6 +137,10 @@ typedef struct ctr_batch {
                                   definite.  Exact when the sizes are constant and signal and
                                   positions per-feature variables (the default modes).  NaN for
                                   clusters of the large-cluster path (> 64 features). */
+  double* result_rows;         /* [N, n_params + 1] or NULL: params_out and, last column, the cost of
+                                  the row's cluster -- the rows of the result table (refine.py:426-427)
+                                  in one block, written when the batch is done: what a pipeline sends
+                                  on (the multi-GPU gather) without another pass over the outputs */
 } ctr_batch;
 
 typedef struct ctr_handle ctr_handle;
@@ -217,6 +221,12 @@ typedef struct ctr_synth {
   uint64_t seed;               /* of the noise */
 } ctr_synth;
 int ctr_draw_frames_device(ctr_handle* h, const ctr_synth* s, void* frames_out, void* hip_stream);
+
+/* Has the last ctr_refine_batch_device call of this handle finished on the device?  1 yes (also
+ * when there was none), 0 still running, -1 error.  Never blocks: lets a pipeline that keeps
+ * several batches in flight hand finished batches on (e.g. to the result gather) from the host
+ * without parking a stream in a device-side wait. */
+int ctr_query_done(ctr_handle* h);
 
 /* Block until the work queued by the *_device calls on `hip_stream` is done. */
 int ctr_synchronize(ctr_handle* h, void* hip_stream);

@@ -334,6 +334,25 @@ def test_too_large_cluster_is_data_not_error(engine):
     assert_equal(prep.batch.params_out, prep.batch.params)
 
 
+def test_result_rows_block_written_by_the_engine(engine):
+    """ctr_batch.result_rows: params_out | cost of the row's cluster in one padded block (what the
+    multi-GPU gather sends), equal to the separate outputs."""
+    import torch
+    from clustertracking_amd.device import DeviceBatch
+    frames, f0, truth, opts = workloads.cfg2(4, 0)
+    prep = cta.prepare_batch(f0, cta.ArrayReader(frames), opts['diameter'])
+    n = prep.batch.n_features
+    db = DeviceBatch(prep.problem, prep.batch, device=0, engine=engine, result_rows=n + 5)
+    db.run()
+    torch.cuda.synchronize()
+    rows = db.t['result_rows'].cpu().numpy()
+    hb = db.download()
+    assert_equal(rows[:n, :-1], hb.params_out)
+    assert_equal(rows[:n, -1], np.repeat(hb.cost, np.diff(hb.feat_offset)))
+    assert_equal(rows[n:], 0.)
+    assert engine.query_done()
+
+
 def test_empty_batch_and_bad_descriptor(engine):
     f0 = pd.DataFrame(dict(y=[], x=[], signal=[], size=[]))
     res = cta.refine_leastsq(f0, np.zeros((32, 32), np.uint8), 13)
