@@ -214,17 +214,23 @@ __global__ void __launch_bounds__(WAVE, NF == 1 ? 3 : 1) refine_small_kernel(con
       const float inv_w1 = ND == 3 ? 1.f / (float)wshape[1] : 1.f;
       const bool big_window = npix >= (1 << 21);
       const double bg = vt[0];
-      if constexpr (NF == 1) {
 #ifndef CTR_SMALL_PX
 #define CTR_SMALL_PX 2
 #endif
-        constexpr int PX = CTR_SMALL_PX;
-        // Singles (the bulk of a frame): PX pixels per lane in flight and no branch around
-        // the model -- the chains of dependent f64 operations of the two pixels interleave
-        // (the kernel is latency bound at 4 waves per SIMD); a lane outside the window or the
-        // mask contributes a zero row.  Same sums as the loop below, other order.
+#ifndef CTR_SMALL_PX2
+#define CTR_SMALL_PX2 1
+#endif
+#ifndef CTR_SMALL_BRANCHFREE2
+#define CTR_SMALL_BRANCHFREE2 1
+#endif
+      if constexpr (NF == 1 || CTR_SMALL_BRANCHFREE2) {
+        constexpr int PX = NF == 1 ? CTR_SMALL_PX : CTR_SMALL_PX2;
+        // PX pixels per lane in flight and no branch around the model -- the chains of dependent
+        // f64 operations of the pixels (and of the two features of a pair) interleave: the
+        // kernel is latency bound at 2-3 waves per SIMD; a lane outside the window or a mask
+        // contributes zeros.  Same sums as the loop below, other order.
         for (int base = 0; __any(base < npix_here); base += PX * SG) {
-          double rw[PX][NR], Ek[PX][ND];
+          double rw[PX][NR], Ek[PX][NF][ND];
 #pragma unroll
           for (int u = 0; u < PX; ++u) {
             const int q = base + u * SG + sub;
@@ -245,31 +251,41 @@ __global__ void __launch_bounds__(WAVE, NF == 1 ? 3 : 1) refine_small_kernel(con
               }
             }
             const double pix = valid ? load_pixel(frame, k.frame_dtype, off) : 0.;
-            double rel[ND];
+            bool in[NF], any = false;
+            double gv[NF], tt[NF][ND];
+            double res = pix - bg;
 #pragma unroll
-            for (int a = 0; a < ND; ++a) rel[a] = mco[0][a] - (double)origin[a];
-            const bool in = valid && in_mask<ND>(idx, rel, inv_r2, radius);
-            double r2 = 0., dd[ND];
+            for (int i = 0; i < NF; ++i) {
+              double rel[ND];
 #pragma unroll
-            for (int a = 0; a < ND; ++a) {
-              dd[a] = (double)(idx[a] + origin[a]) - vt[2 + a];
-              r2 += dd[a] * dd[a] * isz2[0][a];
+              for (int a = 0; a < ND; ++a) rel[a] = mco[i][a] - (double)origin[a];
+              in[i] = valid && in_mask<ND>(idx, rel, inv_r2, radius);
+              any = any || in[i];
+              double r2 = 0.;
+#pragma unroll
+              for (int a = 0; a < ND; ++a) {
+                const double dd = (double)(idx[a] + origin[a]) - vt[1 + NF + a * NF + i];
+                tt[i][a] = dd * isz2[i][a];
+                r2 += dd * tt[i][a];
+              }
+              gv[i] = exp(-0.5 * ND * r2);
+              res -= in[i] ? vt[1 + i] * gv[i] : 0.;
             }
-            const double gv = exp(-0.5 * ND * r2);
-            const double sig = vt[1];
-            const double res = (pix - bg) - sig * gv;
-            const bool ok = in && (res == res);
-            P += in ? 1 : 0;
-            const double sng = -sig * (double)ND * gv;
+            const bool ok = any && (res == res);
+            P += any ? 1 : 0;
             rw[u][0] = ok ? -1. : 0.;
-            rw[u][1] = ok ? -gv : 0.;
-#pragma unroll
-            for (int a = 0; a < ND; ++a) {
-              const double t = dd[a] * isz2[0][a];
-              rw[u][2 + a] = ok ? sng * t : 0.;
-              Ek[u][a] = ok ? (double)ND * t : 0.;
-            }
             rw[u][NV] = ok ? res : 0.;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+              const bool oi = ok && in[i];
+              const double sng = -vt[1 + i] * (double)ND * gv[i];
+              rw[u][1 + i] = oi ? -gv[i] : 0.;
+#pragma unroll
+              for (int a = 0; a < ND; ++a) {
+                rw[u][1 + NF + a * NF + i] = oi ? sng * tt[i][a] : 0.;
+                Ek[u][i][a] = oi ? (double)ND * tt[i][a] : 0.;
+              }
+            }
           }
           int e = 0;
 #pragma unroll
@@ -283,16 +299,17 @@ __global__ void __launch_bounds__(WAVE, NF == 1 ? 3 : 1) refine_small_kernel(con
               ++e;
             }
 #pragma unroll
-          for (int a = 0; a < ND; ++a) {
+          for (int i = 0; i < NF; ++i)
 #pragma unroll
-            for (int b = a; b < ND; ++b) {
-              double t = 0.;
+            for (int a = 0; a < ND; ++a)
 #pragma unroll
-              for (int u = 0; u < PX; ++u) t += (rw[u][NV] * rw[u][2 + a]) * Ek[u][b];
-              M[e] += t;
-              ++e;
-            }
-          }
+              for (int b = a; b < ND; ++b) {
+                double t = 0.;
+#pragma unroll
+                for (int u = 0; u < PX; ++u) t += (rw[u][NV] * rw[u][1 + NF + a * NF + i]) * Ek[u][i][b];
+                M[e] += t;
+                ++e;
+              }
         }
       } else
       for (int base = 0; __any(base < npix_here); base += SG) {
