@@ -1315,7 +1315,9 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
       for (int e = lane; e < n * NP; e += WAVE) pout[e] = cur[(e / NP) * CTR_MAX_PARAMS + (e % NP)];
     if (k.params_std != nullptr) {
       // refine.py:400-406: std = sqrt(2 diag(inv(Hessian of F))) at the solution, all variables
-      // free: std_j = sqrt(P norm [(J^T J + Q)^-1]_jj).  Mp and Uc belong to the accepted point v.
+      // free: std_j = sqrt(P norm [(J^T J + Q)^-1]_jj).  Mp belongs to the accepted point v; Q =
+      // sum_p res_p d2res_p/dv dv in ALL variables is summed here in one more pass over the
+      // window (oracle: full_second_order), whatever the parameter modes.
       double* sd = vt;   // (free now)
       bool pd = ok && n > 0;
       if (pd) {
@@ -1324,17 +1326,126 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           while (tri(a + 1) <= e) ++a;
           while (tri(a) > e) --a;
           const int b = e - tri(a);
-          double h = Msym(Mp, a + 1, b + 1);
-          if (newton_on) {
-            const int ia = vinfo[a], ib = vinfo[b];
-            const int ka = (ia & 7) - 1, kb = (ib & 7) - 1;
-            if (ia >= 0 && ((ia ^ ib) >> 3) == 0 && ka >= 0 && kb >= 0 && ka + kb > 0) {
-              const int k0 = ka < kb ? ka : kb, k1 = ka < kb ? kb : ka;
-              const int idx = k0 == 0 ? k1 - 1 : ND + ((k0 - 1) * ND - ((k0 - 1) * (k0 - 2)) / 2 + (k1 - k0));
-              h += Uc[(ia >> 3) * QT + idx];
+          Hp[e] = Msym(Mp, a + 1, b + 1);
+        }
+        fill_fpar(v, true);
+        wsync();
+        // per feature the second derivatives of m = s g, g = exp(E), in parameter space
+        // (signal, centres, sizes): m_s,t = g E_t, m_t,u = s g (E_t E_u + E_tu); entry (t <= u) of
+        // the PW x PW block at PWI(t, u); lane e = PW t + u adds it to the packed H at the
+        // variables the two parameters map to
+        constexpr int PW = 1 + ND + NSZ, NW = PW * (PW + 1) / 2, NG = (NW + 3) / 4;
+        double* wsum = cv;   // 4 * NG <= 28 doubles of the constraint scratch (free now)
+        int origin[ND], wshape[ND];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) { origin[a] = ctl[1 + a]; wshape[a] = ctl[4 + a]; }
+        const int w1 = wshape[ND - 2], w2 = wshape[ND - 1];
+        const int npix = (ND == 3 ? wshape[0] : 1) * w1 * w2;
+        const double bg = par(v, 0, 0);
+        const int et = lane / PW, eu = lane - et * PW;
+        const int widx = et <= eu ? et * PW - (et * (et - 1)) / 2 + (eu - et)
+                                  : eu * PW - (eu * (eu - 1)) / 2 + (et - eu);
+        for (int base = 0; base < npix; base += WAVE) {
+          const int q = base + lane;
+          const bool valid = q < npix;
+          int idx[ND];
+          size_t off;
+          {
+            const int t = q / w2, x = q - t * w2;
+            if (ND == 3) {
+              const int z = t / w1, y = t - z * w1;
+              idx[0] = z; idx[1] = y; idx[ND - 1] = x;
+              off = ((size_t)(z + origin[0]) * fshape[1] + (y + origin[1])) * fshape[ND - 1] + (x + origin[ND - 1]);
+            } else {
+              idx[0] = t; idx[ND - 1] = x;
+              off = (size_t)(t + origin[0]) * fshape[ND - 1] + (x + origin[ND - 1]);
             }
           }
-          Hp[e] = h;
+          unsigned long long mine = 0ull;
+          double model = 0.;
+          for (int i = 0; i < n; ++i) {
+            double rel[ND];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) rel[a] = mco[i * 3 + a] - (double)origin[a];
+            if (valid && in_mask<ND>(idx, rel, inv_r2, radius)) {
+              const double* f = fpar + i * FP;
+              double r2 = 0.;
+#pragma unroll
+              for (int a = 0; a < ND; ++a) {
+                const double d = (double)(idx[a] + origin[a]) - f[1 + a];
+                r2 += d * d * f[4 + a];
+              }
+              model += f[0] * exp(-0.5 * ND * r2);
+              mine |= 1ull << i;
+            }
+          }
+          double resg = 0.;
+          if (mine != 0ull) {
+            const double res = load_pixel(frame, k.frame_dtype, off) - bg - model;
+            resg = res == res ? res : 0.;  // nansum
+          }
+          for (int i = 0; i < n; ++i) {
+            const bool in = ((mine >> i) & 1ull) != 0ull;
+            if (__ballot(in) == 0ull) continue;
+            const double* f = fpar + i * FP;
+            double E1[PW], dd[ND], i2z[ND], q2 = 0., r2 = 0.;
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              dd[a] = (double)(idx[a] + origin[a]) - f[1 + a];
+              i2z[a] = -0.5 * f[10 + a];   // 1 / size^3
+              q2 += dd[a] * dd[a];
+              r2 += dd[a] * dd[a] * f[4 + a];
+            }
+            const double G = in ? exp(-0.5 * ND * r2) : 0.;
+            const double sg = f[0] * G, mr = -resg;   // d2res = -d2m
+            E1[0] = 0.;
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              E1[1 + a] = (double)ND * dd[a] * f[4 + a];
+              if (!ISO) E1[(1 + ND + a) % PW] = (double)ND * dd[a] * dd[a] * i2z[a];
+            }
+            if (ISO) E1[1 + ND] = (double)ND * q2 * i2z[0];
+            auto hval = [&](int t, int u) -> double {   // t <= u, compile-time after unrolling
+              if (u == 0) return 0.;
+              if (t == 0) return G * E1[u];
+              double h = sg * (E1[t] * E1[u]), e2 = 0.;
+              const int a = t - 1;
+              if (u <= ND) {
+                if (t == u) e2 = -(double)ND * f[4 + a];
+              } else if (t <= ND) {
+                if (ISO) e2 = -2. * ND * dd[a] * i2z[0];
+                else if (u - 1 - ND == a) e2 = -2. * ND * dd[a] * i2z[a];
+              } else {
+                if (ISO) e2 = -3. * ND * q2 * f[4] * f[4];
+                else if (t == u) {
+                  const int b = t - 1 - ND;
+                  e2 = -3. * ND * dd[b] * dd[b] * f[4 + b] * f[4 + b];
+                }
+              }
+              return h + sg * e2;
+            };
+            double hv[4 * NG];
+            {
+              int e = 0;
+#pragma unroll
+              for (int t = 0; t < PW; ++t)
+#pragma unroll
+                for (int u = t; u < PW; ++u) hv[e++] = mr * hval(t, u);
+#pragma unroll
+              for (; e < 4 * NG; ++e) hv[e] = 0.;
+            }
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) {
+              const double t4 = wave_sum4(hv[4 * gq], hv[4 * gq + 1], hv[4 * gq + 2], hv[4 * gq + 3], lane);
+              if ((lane & 15) == 0) wsum[4 * gq + (lane >> 4)] = t4;
+            }
+            wsync();
+            if (lane < PW * PW) {
+              const int ct = L.vidx(1 + et, i), cu = L.vidx(1 + eu, i);
+              if (ct >= 0 && cu >= 0 && ct >= cu) Hp[tri(ct) + cu] += wsum[widx];
+            }
+            wsync();
+          }
         }
         wsync();
         pd = chol_factor_w(Hp, dl, nv, lane);

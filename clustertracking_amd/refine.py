@@ -93,18 +93,6 @@ def prepare_batch(f, reader, diameter, separation=None, fit_function='gauss',
         raise NotImplementedError("param modes 'particle'/'frame' are not "
                                   "implemented (reference refine.py:339-340)")
     cons = engine_constraint(constraints, ndim)
-    if compute_error:
-        # refine.py:400-406 takes the Hessian of the objective by finite differences; the engine
-        # has its second derivatives w.r.t. signal and positions exactly, none w.r.t. sizes
-        names = ff.params
-        size_modes = [m for nme, m in zip(names, modes) if nme.startswith('size')]
-        pos_modes = [modes[names.index(c)] for c in pos_columns]
-        if any(m != 0 for m in size_modes) or modes[names.index('signal')] != 1 or \
-                any(m != 1 for m in pos_modes):
-            raise NotImplementedError(
-                "compute_error needs constant sizes and per-feature signal and positions "
-                "(the default modes): the engine's Hessian is exact for those only")
-
     f = find_clusters(f, separation, pos_columns, t_column, labels=cluster_labels,
                       device=device)  # makes a copy
     if param_val is not None:
@@ -227,7 +215,8 @@ def refine_leastsq(f, reader, diameter, separation=None, fit_function='gauss',
       fallback to hand them to).
     * ``compute_error``: the ``'<param>_std'`` columns come from the exact second
       derivatives of the objective (the reference differentiates numerically with
-      numdifftools); supported with constant sizes and per-feature signal and positions.
+      numdifftools), for every ``param_mode``; clusters of more than 64 features or 127
+      variables (the large-cluster kernel) get NaN there.
     * A cluster whose coordinates are all outside the frame, or that has
       non-finite parameters, gets ``cost = NaN`` (the reference means to do
       that, but crashes with IndexError at refine.py:417).

@@ -134,9 +134,9 @@ typedef struct ctr_batch {
                                   constraints ignored, as there); here from the exact second
                                   derivatives instead of finite differences.  NaN for constant
                                   parameters, failed clusters and a Hessian that is not positive
-                                  definite.  Exact when the sizes are constant and signal and
-                                  positions per-feature variables (the default modes).  NaN for
-                                  clusters of the large-cluster path (> 64 features). */
+                                  definite.  Every parameter mode (second derivatives w.r.t.
+                                  signal, centres and sizes).  NaN for clusters of the
+                                  large-cluster path (> 64 features). */
   double* result_rows;         /* [N, n_params + 1] or NULL: params_out and, last column, the cost of
                                   the row's cluster -- the rows of the result table (refine.py:426-427)
                                   in one block, written when the batch is done: what a pipeline sends

@@ -784,6 +784,106 @@ done:
   return out;
 }
 
+/* sum_p res_p d2res_p/dv dv over ALL variables (the part of the Hessian of S/2 that J^T J
+ * lacks), for any parameter modes.  Per feature the second derivatives of its model
+ * m = s g, g = exp(E), E = -(nd/2) sum_a (x_a - c_a)^2 / size_a^2 (fitfunc.py:112-118) are summed
+ * in parameter space (signal, centres, sizes):
+ *   m_s,t = g E_t      m_t,u = s g (E_t E_u + E_tu)      m_s,s = 0
+ * and then added to the rows/columns of the variables these parameters map to
+ * (vect_to_params, fitfunc.py:266-315: a shared variable collects every feature's block).
+ * Qf[nv*nv].  Used for compute_error only (solution_std); the solver keeps its own Q. */
+static void full_second_order(const ctx_t* c, const double* v, double* Qf) {
+  const layout_t* L = &c->L;
+  const int nd = L->nd, nv = L->nv, n = L->n, np = L->np;
+  const int iso = c->p->isotropic;
+  const int nsz = L->nsz, pw = 1 + nd + nsz;
+  const int64_t* fshape = c->b->shape;
+  const int dtype = c->b->frame_dtype;
+  const double bg = par(c, v, 0, 0);
+  const int w0 = nd == 3 ? c->wshape[0] : 1, w1 = c->wshape[nd - 2], w2 = c->wshape[nd - 1];
+  double (*W)[7][7] = calloc((size_t)(n > 0 ? n : 1), sizeof(double) * 49);
+  struct cf_t { int i; double h[7][7]; }* cf = malloc(sizeof(struct cf_t) * (size_t)(n > 0 ? n : 1));
+  memset(Qf, 0, sizeof(double) * nv * nv);
+  for (int z = 0; z < w0; ++z)
+    for (int y = 0; y < w1; ++y)
+      for (int x = 0; x < w2; ++x) {
+        int idx[3], ncf = 0;
+        double mesh[3], model = 0.;
+        size_t off;
+        if (nd == 3) {
+          idx[0] = z; idx[1] = y; idx[2] = x;
+          off = ((size_t)(z + c->origin[0]) * fshape[1] + (y + c->origin[1])) * fshape[2] + (x + c->origin[2]);
+        } else {
+          idx[0] = y; idx[1] = x;
+          off = (size_t)(y + c->origin[0]) * fshape[1] + (x + c->origin[1]);
+        }
+        for (int a = 0; a < nd; ++a) mesh[a] = (double)(idx[a] + c->origin[a]);
+        for (int i = 0; i < n; ++i) {
+          double E1[7], dd[3], i2[3], isz[3], q = 0., r2 = 0.;
+          double (*h)[7];
+          if (!in_mask(nd, idx, c->mcoords + i * nd, c->origin, c->p->radius)) continue;
+          const double sig = par(c, v, i, 1);
+          for (int a = 0; a < nd; ++a) {
+            const double sz = par(c, v, i, iso ? 2 + nd : 2 + nd + a);
+            dd[a] = mesh[a] - par(c, v, i, 2 + a);
+            isz[a] = 1. / sz;
+            i2[a] = isz[a] * isz[a];
+            q += dd[a] * dd[a];
+            r2 += dd[a] * dd[a] * i2[a];
+          }
+          const double G = exp(-0.5 * nd * r2);
+          model += sig * G;
+          cf[ncf].i = i;
+          h = cf[ncf].h;
+          ++ncf;
+          memset(h, 0, sizeof(double) * 49);
+          /* first derivatives of E: [0] unused (signal), [1+a] centre a, [1+nd+..] sizes */
+          E1[0] = 0.;
+          for (int a = 0; a < nd; ++a) E1[1 + a] = nd * dd[a] * i2[a];
+          if (iso) E1[1 + nd] = nd * q * i2[0] * isz[0];
+          else for (int a = 0; a < nd; ++a) E1[1 + nd + a] = nd * dd[a] * dd[a] * i2[a] * isz[a];
+          for (int t = 1; t < pw; ++t) {
+            h[0][t] = h[t][0] = G * E1[t];
+            for (int u = 1; u < pw; ++u) h[t][u] = sig * G * (E1[t] * E1[u]);
+          }
+          /* second derivatives of E */
+          for (int a = 0; a < nd; ++a) {
+            h[1 + a][1 + a] += sig * G * (-(double)nd * i2[a]);
+            if (iso) {
+              const double e = -2. * nd * dd[a] * i2[0] * isz[0];
+              h[1 + a][1 + nd] += sig * G * e;
+              h[1 + nd][1 + a] += sig * G * e;
+            } else {
+              const double e = -2. * nd * dd[a] * i2[a] * isz[a];
+              h[1 + a][1 + nd + a] += sig * G * e;
+              h[1 + nd + a][1 + a] += sig * G * e;
+              h[1 + nd + a][1 + nd + a] += sig * G * (-3. * nd * dd[a] * dd[a] * i2[a] * i2[a]);
+            }
+          }
+          if (iso) h[1 + nd][1 + nd] += sig * G * (-3. * nd * q * i2[0] * i2[0]);
+        }
+        if (!ncf) continue;
+        const double res = pixel(c->frame, dtype, off) - bg - model;
+        if (res != res) continue; /* nansum */
+        for (int f = 0; f < ncf; ++f)
+          for (int t = 0; t < pw; ++t)
+            for (int u = 0; u < pw; ++u) W[cf[f].i][t][u] -= res * cf[f].h[t][u]; /* d2res = -d2m */
+      }
+  for (int i = 0; i < n; ++i)
+    for (int t = 0; t < pw; ++t) {
+      const int bt = L->var_of[1 + t];
+      if (bt < 0) continue;
+      const int ct = bt + (L->per_feat[1 + t] ? i : 0);
+      for (int u = 0; u < pw; ++u) {
+        const int bu = L->var_of[1 + u];
+        if (bu < 0) continue;
+        Qf[ct * nv + bu + (L->per_feat[1 + u] ? i : 0)] += W[i][t][u];
+      }
+    }
+  (void)np;
+  free(W); free(cf);
+}
+
 /* refine.py:400-406: std = sqrt(2 diag(inv(Hessian of F))) at the solution, all variables
  * free.  Hessian of F = 2 (J^T J + Q) / (P norm), so std_i = sqrt(P norm [(J^T J + Q)^-1]_ii).
  * Returns 0 (and NaNs) when the matrix is not positive definite. */
@@ -794,9 +894,8 @@ static int solution_std(const ctx_t* c, const double* v, double norm, double* st
   double S;
   long P;
   int ok;
-  int newton = use_newton && c->p->modes[1] == CTR_MODE_VAR;
-  for (int a = 0; a < c->L.nd; ++a) newton = newton && c->p->modes[2 + a] == CTR_MODE_VAR;
-  eval_cluster(c, v, &S, g, A, newton ? Q : NULL, &P);
+  eval_cluster(c, v, &S, g, A, NULL, &P);
+  full_second_order(c, v, Q);
   for (int i = 0; i < nv * nv; ++i) A[i] += Q[i];
   ok = cholesky(A, nv, nv);
   for (int i = 0; i < nv; ++i) {
@@ -998,7 +1097,8 @@ int ctro_objective(const ctr_problem* p, const ctr_batch* b, int64_t cl, double*
 
 /* Model Hessian of F at v_in (masks at the start coordinates, as ctro_objective):
  * hess[nv*nv] = 2 (J^T J + Q) / (P norm), with Q the exact second-order part that solve()
- * adds for (signal, positions) of every feature when exact != 0.  Test hook: a finite
+ * adds for (signal, positions) of every feature when exact == 1, the second-order part in all
+ * variables (full_second_order, any modes) when exact == 2.  Test hook: a finite
  * difference of ctro_objective's gradient must reproduce it.  Returns nv. */
 int ctro_hessian(const ctr_problem* p, const ctr_batch* b, int64_t cl, const double* v_in,
                  int exact, double* hess) {
@@ -1028,7 +1128,8 @@ int ctro_hessian(const ctr_problem* p, const ctr_batch* b, int64_t cl, const dou
     const int nv = c.L.nv;
     double* A = malloc(sizeof(double) * nv * nv);
     double* Q = calloc((size_t)nv * nv, sizeof(double));
-    eval_cluster(&c, vect, &S, grad, A, exact ? Q : NULL, &P);
+    eval_cluster(&c, vect, &S, grad, A, exact == 1 ? Q : NULL, &P);
+    if (exact == 2) full_second_order(&c, vect, Q);
     const double fm = fmax[b->frame_index[cl]];
     const double norm = fm * fm / p->residual_factor;
     for (int i = 0; i < nv * nv; ++i) hess[i] = 2. * (A[i] + Q[i]) / (double)P / norm;

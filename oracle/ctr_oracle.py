@@ -106,7 +106,8 @@ def objective(problem, batch, cluster, v_in=None):
 
 def hessian(problem, batch, cluster, v_in=None, exact=True):
     """Model Hessian of F at ``v_in`` (or the packed start vector): 2 (J^T J + Q) / (P norm),
-    Q = the exact second-order part of solve() for (signal, positions); exact=False -> J^T J only."""
+    Q = the exact second-order part of solve() for (signal, positions); exact=False -> J^T J only;
+    exact='full' -> the second-order part in ALL variables, any modes (what compute_error uses)."""
     from clustertracking_amd import _abi
     lib = load()
     b = batch.as_struct()
@@ -117,7 +118,7 @@ def hessian(problem, batch, cluster, v_in=None, exact=True):
     nv = lib.ctro_hessian(C.byref(problem), C.byref(b), int(cluster),
                           None if v_in is None else
                           np.ascontiguousarray(v_in, dtype=np.float64).ctypes.data,
-                          int(bool(exact)), H.ctypes.data)
+                          2 if exact == 'full' else int(bool(exact)), H.ctypes.data)
     if nv < 0:
         raise ValueError("ctro_hessian failed (%d)" % nv)
     return H.reshape(-1)[:nv * nv].reshape(nv, nv).copy()

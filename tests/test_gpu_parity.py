@@ -446,7 +446,10 @@ def test_random_configurations_vs_oracle(engine, oracle, block):
     assert n_ok > 0
 
 
-@pytest.mark.parametrize("name", ['cfg1_triple', 'cfg2_frame_noisy', 'aniso3d_default', 'cfg5_dense'])
+@pytest.mark.parametrize("name", ['cfg1_triple', 'cfg2_frame_noisy', 'aniso3d_default', 'cfg5_dense',
+                                  'iso2d_sizevar', 'aniso2d_sizevar', 'aniso3d_sizevar',
+                                  'iso2d_signal_cluster', 'iso2d_signal_const', 'hard_bg_at_bound_modes',
+                                  'hard_cons_trimer_sizecluster', 'dimer_constrained_noisy'])
 def test_parameter_standard_deviations_engine_vs_oracle(engine, oracle, name):
     """ctr_batch.params_std (compute_error, refine.py:400-406): the engine's values equal the
     oracle's (pinned in tests/test_solver_model.py against a finite-difference Hessian)."""
@@ -477,9 +480,12 @@ def test_compute_error_through_the_host_api(engine):
         assert col in res and np.isfinite(res[col][~np.isnan(res['cost'])]).all()
     assert 'size_std' not in res          # constant parameter (refine.py:309-311)
     assert 0.005 < res['x_std'].median() < 0.2     # S/N 10, size 3: a few hundredths of a pixel
-    with pytest.raises(NotImplementedError):
-        cta.refine_leastsq(case.f0.copy(), case.reader(), diameter, compute_error=True,
-                           param_mode={'size': 'var'})
+    # free sizes: their standard deviations come too (second derivatives w.r.t. sizes)
+    res = cta.refine_leastsq(case.f0.copy(), case.reader(), diameter, compute_error=True,
+                             param_mode={'size': 'var'})
+    good = ~np.isnan(res['cost'])
+    assert np.isfinite(res['size_std'][good]).mean() > 0.95
+    assert 0.005 < res['size_std'][good].median() < 0.3
 
 
 def test_device_path_is_ordered_with_torchs_default_stream(engine, cfg2_full):

@@ -116,11 +116,13 @@ def test_unsupported_is_loud(oracle):
     run = _cases.oracle_runner()
     for kw in (dict(param_mode=dict(signal='global')), dict(fit_function='ring'),
                dict(fit_function='disc'), dict(noise_size=1),
-               dict(compute_error=True, param_mode=dict(size='var')),   # exact Hessian: sizes const only
-               dict(compute_error=True, param_mode=dict(signal='cluster')),
                dict(fit_function=dict(params=[], func=None))):
         with pytest.raises(NotImplementedError):
             _cases.refine_leastsq(f0.copy(), im, 13, _run_batch=run, **kw)
+    # compute_error goes with every param_mode (second derivatives in all variables)
+    for mode, col in ((dict(size='var'), 'size_std'), (dict(signal='cluster'), 'signal_std')):
+        res = _cases.refine_leastsq(f0.copy(), im, 13, compute_error=True, param_mode=mode, _run_batch=run)
+        assert np.isfinite(res[col]).all() and (res[col] > 0).all()
     with pytest.raises(ValueError):
         _cases.refine_leastsq(f0.copy(), im, 13, fit_function='nonsense', _run_batch=run)
     with pytest.raises(ValueError):

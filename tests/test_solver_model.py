@@ -46,6 +46,27 @@ def test_exact_hessian_equals_finite_differences_of_the_gradient(name):
     assert (np.abs(Hgn - Hn) / scale).max() > 1e-3
 
 
+@pytest.mark.parametrize("name", ['cfg1_triple', 'iso2d_sizevar', 'aniso2d_sizevar', 'aniso3d_sizevar',
+                                  'iso2d_signal_cluster', 'iso2d_signal_const', 'hard_bg_at_bound_modes',
+                                  'hard_cons_trimer_sizecluster'])
+def test_full_second_order_equals_finite_differences_for_any_modes(name):
+    """The Hessian that compute_error inverts (solution_std -> full_second_order): every second
+    derivative of the residual, whatever the parameter modes (free / shared sizes, shared /
+    constant signal)."""
+    case = _cases.Case(name)
+    prep = case.prepare()
+    b = prep.batch
+    cluster = int(np.argmax(np.diff(b.feat_offset)))
+    F, v, g, bounds, origin, wshape, P = ctr_oracle.objective(prep.problem, b, cluster)
+    v = v + 0.05 * np.cos(np.arange(len(v)))
+    H = ctr_oracle.hessian(prep.problem, b, cluster, v, exact='full')
+    Hn = _numeric_hessian(prep.problem, b, cluster, v)
+    scale = np.sqrt(np.outer(np.abs(np.diag(Hn)), np.abs(np.diag(Hn)))) + 1e-12
+    assert np.abs(H - Hn).max() / scale.max() < 1e-6
+    assert (np.abs(H - Hn) / scale).max() < 1e-4
+    assert np.array_equal(H, H.T)
+
+
 def test_exact_part_is_limited_to_signal_and_positions_when_sizes_vary():
     case = _cases.Case('iso2d_sizevar')
     prep = case.prepare()
@@ -123,7 +144,8 @@ def _pack(problem, batch, cluster, table):
     return out
 
 
-@pytest.mark.parametrize("name", ['cfg1_triple', 'cfg2_frame_noisy', 'aniso3d_default'])
+@pytest.mark.parametrize("name", ['cfg1_triple', 'cfg2_frame_noisy', 'aniso3d_default', 'iso2d_sizevar',
+                                  'aniso2d_sizevar', 'iso2d_signal_cluster', 'iso2d_signal_const'])
 def test_parameter_standard_deviations(name):
     """compute_error (refine.py:400-406): sqrt(2 diag(inv(Hessian of F))) at the solution.  The
     reference takes the Hessian by finite differences (numdifftools, absent here: parity with
