@@ -7,8 +7,9 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_NDIM = 3
+MAX_NOISE_SIZE = 4.0
 MAX_PARAMS = 8
 MAX_VARS = 127
 
@@ -49,7 +50,8 @@ class Problem(C.Structure):
         ('max_iter', C.c_int32), ('solver_maxiter', C.c_int32), ('flags', C.c_int32),
         ('constraint_dist', C.c_double * MAX_NDIM), ('max_shift', C.c_double),
         ('max_rms_dev', C.c_double), ('residual_factor', C.c_double),
-        ('xtol', C.c_double), ('ftol', C.c_double), ('reserved1', C.c_double),
+        ('xtol', C.c_double), ('ftol', C.c_double), ('threshold', C.c_double),
+        ('noise_size', C.c_double * MAX_NDIM),
     ]
 
 
@@ -78,8 +80,9 @@ class Synth(C.Structure):
 
 def make_problem(ndim, isotropic, modes, radius, constraint=None, max_iter=10,
                  max_shift=1., max_rms_dev=1., residual_factor=100000.,
-                 solver_maxiter=100, xtol=0., ftol=0.):
-    """Fill a ``ctr_problem``.  ``constraint`` = None or (kind, dist[ndim])."""
+                 solver_maxiter=100, xtol=0., ftol=0., noise_size=None, threshold=None):
+    """Fill a ``ctr_problem``.  ``constraint`` = None or (kind, dist[ndim]); ``noise_size`` = None
+    or one sigma per axis (refine.py:37-40)."""
     p = Problem()
     p.ndim = int(ndim)
     p.isotropic = int(bool(isotropic))
@@ -103,6 +106,12 @@ def make_problem(ndim, isotropic, modes, radius, constraint=None, max_iter=10,
     p.residual_factor = float(residual_factor)
     p.xtol = float(xtol)
     p.ftol = float(ftol)
+    if noise_size is not None:
+        for i, sgm in enumerate(noise_size):
+            if not (0 <= float(sgm) <= MAX_NOISE_SIZE):
+                raise ValueError("noise_size must be between 0 and %g" % MAX_NOISE_SIZE)
+            p.noise_size[i] = float(sgm)
+        p.threshold = 0. if threshold is None else float(threshold)   # refine.py:38-39
     return p
 
 

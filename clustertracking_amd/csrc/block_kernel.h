@@ -246,7 +246,9 @@ __device__ unsigned long long g_stamps[16];
 // CONS: the instantiation that takes the clusters with equality constraints (dimers, trimers,
 // tetramers: at most 29 variables, NT <= 2); in the others the constrained code is compiled out
 // (it costs the unconstrained fits registers otherwise: 700 B of scratch per lane, measured).
-template <int ND, bool ISO, int NT, int W, bool CONS>
+// LP: the instantiation for problems with a lowpass of the window (ctr_problem.noise_size): every
+// pixel value is the filtered one, computed from the raw frame where it is needed.
+template <int ND, bool ISO, int NT, int W, bool CONS, bool LP = false>
 __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
 #ifdef CTR_STAMPS
   unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
@@ -724,7 +726,11 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         }
         bool any = false;
         // the pixel is fetched up front (its latency hides behind the mask tests)
-        const double pix = (valid && cand != 0ull) ? load_pixel(frame, k.frame_dtype, off) : 0.;
+        double pix = 0.;
+        if (valid && cand != 0ull) {
+          if constexpr (LP) pix = lowpass_pixel<ND>(frame, k.frame_dtype, fshape, origin, wshape, idx, k.lp_w, k.lp_half, k.prob.threshold);
+          else pix = load_pixel(frame, k.frame_dtype, off);
+        }
         unsigned long long todo = cand | prev_cand;
         prev_cand = cand;
         double res = 0.;
@@ -1381,7 +1387,10 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           }
           double resg = 0.;
           if (mine != 0ull) {
-            const double res = load_pixel(frame, k.frame_dtype, off) - bg - model;
+            double pixv;
+            if constexpr (LP) pixv = lowpass_pixel<ND>(frame, k.frame_dtype, fshape, origin, wshape, idx, k.lp_w, k.lp_half, k.prob.threshold);
+            else pixv = load_pixel(frame, k.frame_dtype, off);
+            const double res = pixv - bg - model;
             resg = res == res ? res : 0.;  // nansum
           }
           for (int i = 0; i < n; ++i) {

@@ -68,6 +68,10 @@ struct ctr_plan {
   long long* d_ws_off = nullptr;   // [n_clusters] offset in doubles (0 for the other clusters)
   int64_t bin_begin[NBINS + 1] = {0};
   int64_t bin_count[NBINS] = {0};
+  // lowpass of the window (ctr_problem.noise_size): taps per axis on the device (kargs.h: lp_w)
+  bool lowpass = false;
+  double* d_lp_w = nullptr;
+  int lp_half[3] = {0, 0, 0};
 };
 
 struct ctr_handle {
@@ -95,6 +99,10 @@ struct ctr_handle {
   small_fn small_table[2][2][2];  // [ndim-2][iso][nf-1]; singles with 8 lanes per cluster (eight per wavefront)
   small_fn small_wide1[2][2];     // singles with 64 lanes per cluster (large windows)
   small_fn small_bulk2[2][2];     // pairs with 16 lanes per cluster (the bulk of a pairs bin)
+  KernelInfo lp[2][2][MAXNT];     // block kernel with the lowpass of the window: [ndim-2][iso][nt-1]
+  KernelInfo lp_cons[2][2][2];    // ... for constrained clusters, nt = 1, 2
+  bool lp_attr[2][2][MAXNT] = {};
+  bool lp_cons_attr[2][2][2] = {};
   KernelInfo large[2][2];         // refine_large_kernel<ndim, iso>
   bool large_attr[2][2] = {};
   hipEvent_t ev_done = nullptr;   // end of the last ctr_refine_batch_device call of this handle
@@ -141,7 +149,40 @@ int validate(const ctr_problem* p, std::string& msg) {
     for (int a = 0; a < p->ndim; ++a)
       if (!(p->constraint_dist[a] > 0.)) { msg = "constraint distance must be positive"; return CTR_ERR_INVALID; }
   if (!(p->residual_factor > 0.)) { msg = "residual_factor must be positive"; return CTR_ERR_INVALID; }
+  for (int a = 0; a < p->ndim; ++a)
+    if (!(p->noise_size[a] >= 0.) || p->noise_size[a] > CTR_MAX_NOISE_SIZE) {
+      msg = "noise_size must be between 0 and CTR_MAX_NOISE_SIZE";
+      return CTR_ERR_INVALID;
+    }
+  if (p->threshold != p->threshold) { msg = "threshold is NaN"; return CTR_ERR_INVALID; }
   return CTR_OK;
+}
+
+// trackpy.masks.gaussian_kernel(sigma, truncate=4), the taps of the reference's lowpass
+// (preprocessing.py:43).  trackpy is not part of the reference's tree: restated from its
+// published source (lw = int(4 sigma + 0.5); exp(x^2 / (-2 sigma^2)) / sum, numpy's pairwise
+// sum for short arrays); the same code as oracle/ctr_oracle.c:ctro_gaussian_kernel.
+int gaussian_taps(double sigma, double* w) {
+  const int lw = (int)(4.0 * sigma + 0.5), nw = 2 * lw + 1;
+  double sum;
+  for (int i = 0; i < nw; ++i) {
+    const double x = (double)(i - lw);
+    w[i] = std::exp((x * x) / (-2. * (sigma * sigma)));
+  }
+  if (nw < 8) {
+    sum = 0.;
+    for (int i = 0; i < nw; ++i) sum += w[i];
+  } else {
+    double r[8];
+    int i;
+    for (int j = 0; j < 8; ++j) r[j] = w[j];
+    for (i = 8; i < nw - (nw % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += w[i + j];
+    sum = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < nw; ++i) sum += w[i];
+  }
+  for (int i = 0; i < nw; ++i) w[i] /= sum;
+  return lw;
 }
 
 int n_vars(const ctr_problem* p, int n) {
@@ -254,6 +295,8 @@ int ctr_create(ctr_handle** out, int device) {
       for (int nt = 1; nt <= MAXNT; ++nt) {
         const KernelInfo a = di == 0 ? ctr_block_kernel_2d(ii, nt, 0, 0) : ctr_block_kernel_3d(ii, nt, 0, 0);
         const KernelInfo t = di == 0 ? ctr_block_kernel_2d(ii, nt, 1, 0) : ctr_block_kernel_3d(ii, nt, 1, 0);
+        h->lp[di][ii][nt - 1] = ctr_block_kernel_lp(2 + di, ii, nt, 0);
+        if (nt <= 2) h->lp_cons[di][ii][nt - 1] = ctr_block_kernel_lp(2 + di, ii, nt, 1);
         if (nt <= 2)
           for (int tp = 0; tp < 2; ++tp)
             h->cons[di][ii][tp][nt - 1] = di == 0 ? ctr_block_kernel_2d(ii, nt, tp, 1) : ctr_block_kernel_3d(ii, nt, tp, 1);
@@ -307,6 +350,9 @@ int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
     if (p->modes[k2] == CTR_MODE_VAR) ++npf;
     else if (p->modes[k2] != CTR_MODE_CONST) ++nsh;
   }
+  for (int a = 0; a < p->ndim; ++a) plan->lowpass = plan->lowpass || p->noise_size[a] > 0.;
+  // (the lowpass lives in its own instantiations of the block kernel: every cluster goes there)
+  if (plan->lowpass) default_modes = false;
   std::vector<long long> ws_off((size_t)n_clusters, 0);
   long long ws_total = 0;
   for (int64_t c = 0; c < n_clusters; ++c) {
@@ -330,7 +376,7 @@ int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
     }
     if (bin == BIN_LARGE) {
       // the large kernel's 16-column row: [r, shared.., own.., r_o, shared_o..]
-      if (npf < 1 || 2 + 2 * nsh + npf > 16) bin = BIN_TOO_LARGE;
+      if (npf < 1 || 2 + 2 * nsh + npf > 16 || plan->lowpass) bin = BIN_TOO_LARGE;
       else {
         ws_off[(size_t)c] = ws_total;
         ws_total += large_ws((int)n, npf, nsh).total;
@@ -364,6 +410,18 @@ int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
       ctr_plan_destroy(plan);
       return fail(h, CTR_ERR_DEVICE, "cannot upload the plan");
     }
+    if (plan->lowpass) {
+      std::vector<double> taps(3 * LP_STRIDE, 0.);
+      for (int a = 0; a < p->ndim; ++a) {
+        if (p->noise_size[a] > 0.) plan->lp_half[a] = gaussian_taps(p->noise_size[a], taps.data() + a * LP_STRIDE);
+        else taps[(size_t)a * LP_STRIDE] = 1.;   // this axis is not filtered
+      }
+      if (hipMalloc((void**)&plan->d_lp_w, sizeof(double) * taps.size()) != hipSuccess ||
+          hipMemcpy(plan->d_lp_w, taps.data(), sizeof(double) * taps.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        ctr_plan_destroy(plan);
+        return fail(h, CTR_ERR_NOMEM, "cannot upload the lowpass taps");
+      }
+    }
     if (ws_total > 0) {
       if (hipMalloc((void**)&plan->d_ws, sizeof(double) * (size_t)ws_total) != hipSuccess ||
           hipMalloc((void**)&plan->d_ws_off, sizeof(long long) * (size_t)n_clusters) != hipSuccess) {
@@ -386,6 +444,7 @@ void ctr_plan_destroy(ctr_plan* plan) {
   if (plan->d_front) (void)hipFree(plan->d_front);
   if (plan->d_ws) (void)hipFree(plan->d_ws);
   if (plan->d_ws_off) (void)hipFree(plan->d_ws_off);
+  if (plan->d_lp_w) (void)hipFree(plan->d_lp_w);
   delete plan;
 }
 
@@ -438,6 +497,8 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
   k.n_iter = b->n_iter;
   k.params_std = b->params_std;
   k.fmax = h->d_fmax;
+  k.lp_w = plan->lowpass ? plan->d_lp_w : nullptr;
+  for (int a = 0; a < 3; ++a) k.lp_half[a] = plan->lp_half[a];
   const int di = p.ndim == 3 ? 1 : 0, ii = p.isotropic ? 1 : 0;
   // The bins are independent: the big bin of singles runs on the caller's
   // stream, the others on side streams forked from / joined to it by events, so
@@ -471,10 +532,11 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     if (cnt == 0) continue;
     // (2D only: a 3D window has thousands of pixels, more wavefronts per cluster pay there)
     const bool tp = (p.flags & CTR_FLAG_THROUGHPUT) != 0 && p.ndim == 2;
-    kernel_fn fn = tp ? h->table_tp[di][ii][bin] : h->table[di][ii][bin];
-    const size_t bytes = tp ? h->smem_bytes_tp[di][ii][bin] : h->smem_bytes[di][ii][bin];
-    const int threads = tp ? h->block_threads_tp[di][ii][bin] : h->block_threads[di][ii][bin];
-    bool& attr = tp ? h->attr_set_tp[di][ii][bin] : h->attr_set[di][ii][bin];
+    const bool lpk = plan->lowpass;
+    kernel_fn fn = lpk ? h->lp[di][ii][bin].fn : (tp ? h->table_tp[di][ii][bin] : h->table[di][ii][bin]);
+    const size_t bytes = lpk ? h->lp[di][ii][bin].smem : (tp ? h->smem_bytes_tp[di][ii][bin] : h->smem_bytes[di][ii][bin]);
+    const int threads = lpk ? h->lp[di][ii][bin].threads : (tp ? h->block_threads_tp[di][ii][bin] : h->block_threads[di][ii][bin]);
+    bool& attr = lpk ? h->lp_attr[di][ii][bin] : (tp ? h->attr_set_tp[di][ii][bin] : h->attr_set[di][ii][bin]);
     if (!attr) {
       HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
       attr = true;
@@ -491,10 +553,11 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     const int64_t cnt = plan->bin_count[bin];
     if (cnt == 0) continue;
     const int tp = ((p.flags & CTR_FLAG_THROUGHPUT) != 0 && p.ndim == 2) ? 1 : 0;
-    const KernelInfo& ki = h->cons[di][ii][tp][cb];
-    if (!h->cons_attr[di][ii][tp][cb]) {
+    const KernelInfo& ki = plan->lowpass ? h->lp_cons[di][ii][cb] : h->cons[di][ii][tp][cb];
+    bool& cattr = plan->lowpass ? h->lp_cons_attr[di][ii][cb] : h->cons_attr[di][ii][tp][cb];
+    if (!cattr) {
       HIP_TRY(h, hipFuncSetAttribute(ki.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ki.smem));
-      h->cons_attr[di][ii][tp][cb] = true;
+      cattr = true;
     }
     k.order = ord + plan->bin_begin[bin];
     k.n_bin = (int32_t)cnt;

@@ -32,6 +32,47 @@ __device__ __forceinline__ double load_pixel(const void* base, int dtype, size_t
   }
 }
 
+// refine.py:37-40 / preprocessing.py:12-49: pixel idx of the lowpass-filtered WINDOW (origin,
+// wshape), computed from the raw frame on the fly.  The reference correlates the window axis by
+// axis (axis 0 first) with scipy.ndimage.correlate1d(mode='constant', cval=0), in place; written
+// out for one pixel that is the nest below, each level with SciPy's order for a symmetric
+// kernel: centre tap, then the pairs from the outermost inwards.  Values <= threshold -> 0.
+template <int ND>
+__device__ double lowpass_pixel(const void* frame, int dtype, const long* fshape, const int* origin,
+                                             const int* wshape, const int* idx, const double* lp_w,
+                                             const int* lp_half, double threshold) {
+  auto raw = [&](int z, int y, int x) -> double {   // window coordinates; 0 beyond the window
+    if (x < 0 || x >= wshape[ND - 1] || y < 0 || y >= wshape[ND - 2]) return 0.;
+    if (ND == 3 && (z < 0 || z >= wshape[0])) return 0.;
+    const size_t off = ND == 3
+        ? ((size_t)(z + origin[0]) * fshape[1] + (y + origin[1])) * fshape[ND - 1] + (x + origin[ND - 1])
+        : (size_t)(y + origin[0]) * fshape[ND - 1] + (x + origin[ND - 1]);
+    return load_pixel(frame, dtype, off);
+  };
+  const int hz = ND == 3 ? lp_half[0] : 0, hy = lp_half[ND - 2], hx = lp_half[ND - 1];
+  const double *wz = lp_w, *wy = lp_w + (ND - 2) * LP_STRIDE, *wx = lp_w + (ND - 1) * LP_STRIDE;
+  const int z0 = ND == 3 ? idx[0] : 0, y0 = idx[ND - 2], x0 = idx[ND - 1];
+  auto along_z = [&](int y, int x) -> double {
+    if (ND != 3) return raw(0, y, x);
+    double t = raw(z0, y, x) * wz[hz];
+    for (int j = -hz; j < 0; ++j) t += (raw(z0 + j, y, x) + raw(z0 - j, y, x)) * wz[hz + j];
+    return t;
+  };
+  auto along_y = [&](int x) -> double {
+    if (x < 0 || x >= wshape[ND - 1]) return 0.;
+    double t = along_z(y0, x) * wy[hy];
+    for (int j = -hy; j < 0; ++j) {
+      const double a = y0 + j >= 0 ? along_z(y0 + j, x) : 0.;
+      const double b = y0 - j < wshape[ND - 2] ? along_z(y0 - j, x) : 0.;
+      t += (a + b) * wy[hy + j];
+    }
+    return t;
+  };
+  double t = along_y(x0) * wx[hx];
+  for (int j = -hx; j < 0; ++j) t += (along_y(x0 + j) + along_y(x0 - j)) * wx[hx + j];
+  return t > threshold ? t : 0.;
+}
+
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);

@@ -36,7 +36,14 @@ struct KArgs {
   // split_part 2: entries [*split, n_bin)
   const int32_t* split;
   int32_t split_part;
+  // lowpass of the window (ctr_problem.noise_size): taps of axis a at lp_w[a * LP_STRIDE + 0 ..
+  // 2 * lp_half[a]], normalised; an unfiltered axis has lp_half 0 and the single tap 1.
+  // nullptr = no lowpass.  Only the LP instantiations of the block kernel read them.
+  int32_t lp_half[3];
+  const double* lp_w;
 };
+
+constexpr int LP_STRIDE = 40;   // >= 2 * 16 + 1 taps (CTR_MAX_NOISE_SIZE = 4)
 
 // a kernel of another translation unit: host-side handle for hipLaunchKernel /
 // hipFuncSetAttribute, dynamic LDS bytes and workgroup size
@@ -79,6 +86,8 @@ __host__ __device__ inline LargeWs large_ws(int n, int npf, int ns) {
 // cons != 0: the instantiation for clusters with equality constraints (nt = 1, 2 only)
 KernelInfo ctr_block_kernel_2d(int iso, int nt, int throughput, int cons);
 KernelInfo ctr_block_kernel_3d(int iso, int nt, int throughput, int cons);
+// the same with the lowpass of the window (LP = true); one instantiation per (ndim, iso, nt, cons)
+KernelInfo ctr_block_kernel_lp(int ndim, int iso, int nt, int cons);
 // refine_small_kernel<ND, NF, ISO, SG>(KArgs, int* counter); nullptr if not instantiated
 const void* ctr_small_kernel(int ndim, int nf, int iso, int sg);
 KernelInfo ctr_large_kernel(int ndim, int iso);

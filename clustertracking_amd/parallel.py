@@ -54,9 +54,8 @@ def refine_leastsq_sharded(f, reader, diameter, group=None, device=None,
     options.update(kwargs.pop('options', None) or {})
     kwargs.pop('method', None)
     kwargs.pop('tol', None)
-    if kwargs.pop('noise_size', None) is not None:
-        raise NotImplementedError("noise_size is not implemented by the MI355X engine")
-    kwargs.pop('threshold', None)     # only used together with noise_size (refine.py:37-40)
+    if kwargs.get('noise_size') is None:
+        kwargs.pop('threshold', None)     # only used together with noise_size (refine.py:37-40)
     backend = dist.get_backend(group)
     if device is None:
         if 'LOCAL_RANK' in os.environ:

@@ -67,7 +67,7 @@ def prepare_batch(f, reader, diameter, separation=None, fit_function='gauss',
                   pos_columns=None, t_column='frame', max_iter=10, max_shift=1,
                   max_rms_dev=1., residual_factor=100000., solver_maxiter=100,
                   xtol=0., ftol=0., cluster_labels='reference', device=0,
-                  compute_error=False):
+                  compute_error=False, noise_size=None, threshold=None):
     """Host-side set-up of one refine call (reference refine.py:242-341)."""
     if pos_columns is None:
         pos_columns = guess_pos_columns(f)
@@ -139,7 +139,9 @@ def prepare_batch(f, reader, diameter, separation=None, fit_function='gauss',
                                 max_iter=max_iter, max_shift=max_shift,
                                 max_rms_dev=max_rms_dev,
                                 residual_factor=residual_factor,
-                                solver_maxiter=solver_maxiter, xtol=xtol, ftol=ftol)
+                                solver_maxiter=solver_maxiter, xtol=xtol, ftol=ftol,
+                                noise_size=None if noise_size is None else validate_tuple(noise_size, ndim),
+                                threshold=threshold)
     batch = _abi.HostBatch(frames, frame_index, feat_offset, params[order],
                            low[order], high[order], want_std=bool(compute_error))
     # SciPy raises ValueError for an infeasible box (lower > upper)
@@ -210,9 +212,11 @@ def refine_leastsq(f, reader, diameter, separation=None, fit_function='gauss',
       ``xtol``, ``ftol``, ``device``, ``cluster_labels`` ('reference': ids equal to
       the reference's, labelled on the host; 'device': same partition labelled on
       the GPU, canonical ids).
-    * ``fit_function`` other than ``'gauss'``, ``param_mode`` value
-      ``'global'`` and ``noise_size`` raise ``NotImplementedError`` (there is no CPU
+    * ``fit_function`` other than ``'gauss'`` and ``param_mode`` value
+      ``'global'`` raise ``NotImplementedError`` (there is no CPU
       fallback to hand them to).
+    * ``noise_size`` (the lowpass of every window, refine.py:37-40) up to sigma 4;
+      clusters of more than 64 features get ``cost = NaN`` with it.
     * ``compute_error``: the ``'<param>_std'`` columns come from the exact second
       derivatives of the objective (the reference differentiates numerically with
       numdifftools), for every ``param_mode``; clusters of more than 64 features or 127
@@ -231,17 +235,13 @@ def refine_leastsq(f, reader, diameter, separation=None, fit_function='gauss',
     cluster_labels = kwargs.pop('cluster_labels', 'reference')
     if kwargs:
         raise TypeError("unexpected keyword arguments: %s" % sorted(kwargs))
-    if noise_size is not None:
-        raise NotImplementedError("noise_size (lowpass inside the window) is "
-                                  "not implemented by the MI355X engine")
-
     prep = prepare_batch(f, reader, diameter, separation, fit_function,
                          param_mode, param_val, constraints, bounds,
                          pos_columns, t_column, max_iter, max_shift,
                          max_rms_dev, residual_factor,
                          solver_maxiter=int(options.get('maxiter', 100)),
                          xtol=xtol, ftol=ftol, cluster_labels=cluster_labels, device=device,
-                         compute_error=compute_error)
+                         compute_error=compute_error, noise_size=noise_size, threshold=threshold)
     if prep.batch.n_clusters:
         _run_on_engine(prep.problem, prep.batch, device)
     return write_back(prep)

@@ -27,13 +27,14 @@
 extern "C" {
 #endif
 
-#define CTR_ABI_VERSION 3
+#define CTR_ABI_VERSION 4
 #define CTR_MAX_NDIM 3
 #define CTR_MAX_PARAMS 8 /* background, signal, <=3 positions, <=3 sizes */
 #define CTR_MAX_VARS 127 /* optimiser variables per cluster of the on-chip kernels; larger clusters
                             (or more than 64 features) take the large-cluster path: normal matrix
                             block-sparse in HBM, no limit on features or variables */
-#define CTR_MAX_NEIGHBOURS 48 /* large-cluster path: features whose mask ellipsoids overlap one feature's */
+#define CTR_MAX_NEIGHBOURS 48
+#define CTR_MAX_NOISE_SIZE 4.0   /* lowpass sigma: at most 2 * 16 + 1 taps per axis */ /* large-cluster path: features whose mask ellipsoids overlap one feature's */
 
 /* error codes (return values) */
 enum {
@@ -104,7 +105,15 @@ typedef struct ctr_problem {
   double residual_factor;          /* refine.py:354,379 (default 1e5) */
   double xtol;                     /* relative step tolerance; <= 0 -> 1e-9 */
   double ftol;                     /* relative model-decrease tolerance; <= 0 -> 1e-14 */
-  double reserved1;
+  double threshold;                /* lowpass: filtered values <= threshold become 0
+                                      (refine.py:38-40, preprocessing.py:47; default 0) */
+  double noise_size[CTR_MAX_NDIM]; /* refine.py:37-40: the window of every re-window round is
+                                      correlated, axis by axis, with a normalised Gaussian of this
+                                      sigma truncated at 4 sigma (preprocessing.py:12-49), zero
+                                      beyond the WINDOW edges, before it is fitted; 0 = that axis
+                                      is not filtered, all 0 = no lowpass.  At most
+                                      CTR_MAX_NOISE_SIZE; clusters of more than 64 features or 127
+                                      variables get CTR_STATUS_TOO_LARGE with a lowpass. */
 } ctr_problem;
 
 /* The data of one batch.  All arrays C-contiguous.  For ctr_refine_batch the

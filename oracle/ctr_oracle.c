@@ -53,6 +53,7 @@ typedef struct {
   int origin[3], wshape[3];
   const double* mcoords; /* [n][nd] coordinates the masks are centred on */
   int n_cons;            /* active equality constraints (0 if size mismatch) */
+  double* fwin;          /* lowpass-filtered window [wshape] (refine.py:37-40), NULL without noise_size */
 } ctx_t;
 
 /* ---- small helpers ------------------------------------------------------- */
@@ -94,6 +95,98 @@ static int make_layout(const ctr_problem* p, int n, layout_t* L) {
 int ctro_cluster_n_vars(const ctr_problem* p, int n) {
   layout_t L;
   return make_layout(p, n, &L);
+}
+
+/* ---- lowpass of the window (refine.py:37-40, preprocessing.py:12-49) ------- */
+
+/* trackpy.masks.gaussian_kernel(sigma, truncate=4) -- trackpy (v0.3/0.4, masks.py) is absent
+ * from this image: restated from its published source, PARITY UNPINNED for this function alone:
+ *   lw = int(truncate * sigma + 0.5); x = arange(-lw, lw + 1)
+ *   result = exp(x**2 / (-2 * sigma**2)); return result / sum(result)
+ * w[2*lw+1]; returns lw.  The sum follows numpy's pairwise order for short arrays. */
+int ctro_gaussian_kernel(double sigma, double* w) {
+  const int lw = (int)(4.0 * sigma + 0.5), nw = 2 * lw + 1;
+  double sum;
+  for (int i = 0; i < nw; ++i) {
+    const double x = (double)(i - lw);
+    w[i] = exp((x * x) / (-2. * (sigma * sigma)));
+  }
+  if (nw < 8) {
+    sum = 0.;
+    for (int i = 0; i < nw; ++i) sum += w[i];
+  } else {
+    double r[8];
+    int i;
+    for (int j = 0; j < 8; ++j) r[j] = w[j];
+    for (i = 8; i < nw - (nw % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += w[i + j];
+    sum = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < nw; ++i) sum += w[i];
+  }
+  for (int i = 0; i < nw; ++i) w[i] /= sum;
+  return lw;
+}
+
+/* preprocessing.py:41-49 on a window of doubles, in place: per axis with size > 0
+ * scipy.ndimage.correlate1d(result, kernel, axis, output=result, mode='constant', cval=0)
+ * -- SciPy's loop for a symmetric kernel: centre tap first, then the pairs from the outermost
+ * inwards (ni_filters.c:NI_Correlate1D) -- then values <= threshold become 0 (NaN too). */
+void ctro_lowpass(int nd, const int* wshape, const double* noise_size, double threshold, double* win) {
+  size_t total = 1;
+  int maxlen = 0;
+  for (int a = 0; a < nd; ++a) {
+    total *= (size_t)wshape[a];
+    if (wshape[a] > maxlen) maxlen = wshape[a];
+  }
+  for (int a = 0; a < nd; ++a) {
+    double w[2 * 16 + 1 + 8];
+    if (!(noise_size[a] > 0.)) continue;
+    const int lw = ctro_gaussian_kernel(noise_size[a] > CTR_MAX_NOISE_SIZE ? CTR_MAX_NOISE_SIZE : noise_size[a], w);
+    const int len = wshape[a];
+    size_t stride = 1;
+    for (int b2 = a + 1; b2 < nd; ++b2) stride *= (size_t)wshape[b2];
+    double* line = calloc((size_t)len + 2 * (size_t)lw, sizeof(double));
+    for (size_t start = 0; start < total; ++start) {
+      /* every line along axis a: start = index with coordinate 0 on that axis */
+      if ((start / stride) % (size_t)len != 0) continue;
+      for (int i = 0; i < len; ++i) line[lw + i] = win[start + (size_t)i * stride];
+      for (int i = 0; i < len; ++i) {
+        const double* il = line + lw + i;
+        double t = il[0] * w[lw];
+        for (int jj = -lw; jj < 0; ++jj) t += (il[jj] + il[-jj]) * w[lw + jj];
+        win[start + (size_t)i * stride] = t;
+      }
+    }
+    free(line);
+  }
+  for (size_t i = 0; i < total; ++i) win[i] = win[i] > threshold ? win[i] : 0.;
+}
+
+static int has_lowpass(const ctr_problem* p) {
+  for (int a = 0; a < p->ndim; ++a)
+    if (p->noise_size[a] > 0.) return 1;
+  return 0;
+}
+
+/* the filtered window of this round (c->origin / c->wshape set), or NULL */
+static void make_fwin(ctx_t* c) {
+  const int nd = c->p->ndim;
+  const int64_t* fs = c->b->shape;
+  free(c->fwin);
+  c->fwin = NULL;
+  if (!has_lowpass(c->p)) return;
+  const int w0 = nd == 3 ? c->wshape[0] : 1, w1 = c->wshape[nd - 2], w2 = c->wshape[nd - 1];
+  double* win = malloc(sizeof(double) * (size_t)w0 * w1 * w2);
+  for (int z = 0; z < w0; ++z)
+    for (int y = 0; y < w1; ++y)
+      for (int x = 0; x < w2; ++x) {
+        const size_t off = nd == 3
+            ? ((size_t)(z + c->origin[0]) * fs[1] + (y + c->origin[1])) * fs[2] + (x + c->origin[2])
+            : (size_t)(y + c->origin[0]) * fs[1] + (x + c->origin[1]);
+        win[((size_t)z * w1 + y) * w2 + x] = pixel(c->frame, c->b->frame_dtype, off);
+      }
+  ctro_lowpass(nd, c->wshape, c->p->noise_size, c->p->threshold, win);
+  c->fwin = win;
 }
 
 /* parameter k of feature i at the trial vector v */
@@ -294,7 +387,7 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
           if (!in_mask(nd, idx, c->mcoords + i * nd, c->origin, c->p->radius)) continue;
           if (!any) {
             any = 1;
-            pv = pixel(c->frame, dtype, off);
+            pv = c->fwin ? c->fwin[((size_t)z * w1 + y) * w2 + x] : pixel(c->frame, dtype, off);
             res = pv - bg;
             if (bgvar >= 0) { row[bgvar] = -1.; nz[nnz++] = bgvar; }
           }
@@ -863,7 +956,7 @@ static void full_second_order(const ctx_t* c, const double* v, double* Qf) {
           if (iso) h[1 + nd][1 + nd] += sig * G * (-3. * nd * q * i2[0] * i2[0]);
         }
         if (!ncf) continue;
-        const double res = pixel(c->frame, dtype, off) - bg - model;
+        const double res = (c->fwin ? c->fwin[((size_t)z * w1 + y) * w2 + x] : pixel(c->frame, dtype, off)) - bg - model;
         if (res != res) continue; /* nansum */
         for (int f = 0; f < ncf; ++f)
           for (int t = 0; t < pw; ++t)
@@ -953,7 +1046,7 @@ static void refine_one(const ctr_problem* p, const ctr_batch* b, int64_t cl,
   b->cost[cl] = NAN;
   b->n_rounds[cl] = 0;
   b->n_iter[cl] = 0;
-  c.p = p; c.b = b;
+  c.p = p; c.b = b; c.fwin = NULL;
   if (n <= 0) { b->status[cl] = CTR_STATUS_OUT_OF_BOUNDS; return; }
   make_layout(p, n, &c.L);   /* (the oracle has no size limit; constraints only for n <= 4) */
   for (int i = 0; i < n * np; ++i)
@@ -983,6 +1076,7 @@ static void refine_one(const ctr_problem* p, const ctr_batch* b, int64_t cl,
         break;
       }
       c.mcoords = coords;
+      make_fwin(&c);                                            /* refine.py:37-40 */
       solve_t r = solve(&c, v0, lo, hi, v);
       b->n_iter[cl] += r.iters;
       if (r.P == 0) { status = CTR_STATUS_OUT_OF_BOUNDS; break; }
@@ -1018,6 +1112,7 @@ static void refine_one(const ctr_problem* p, const ctr_batch* b, int64_t cl,
     free(vecs);
     free(cur);
     free(coords);
+    free(c.fwin);
   }
 }
 
@@ -1075,6 +1170,8 @@ int ctro_objective(const ctr_problem* p, const ctr_batch* b, int64_t cl, double*
     for (int a = 0; a < nd; ++a) coords[i * nd + a] = params[i * np + 2 + a];
   if (!window(nd, b->shape, p->radius, coords, n, c.origin, c.wshape)) { free(fmax); free(coords); return -2; }
   c.mcoords = coords;
+  c.fwin = NULL;
+  make_fwin(&c);
   pack_start(&c, params, b->low + (size_t)f0 * np, b->high + (size_t)f0 * np, vect, lo, hi);
   if (v_in) memcpy(vect, v_in, sizeof(double) * c.L.nv); /* evaluate elsewhere, masks stay at p0 */
   A = malloc(sizeof(double) * c.L.nv * c.L.nv);
@@ -1091,7 +1188,7 @@ int ctro_objective(const ctr_problem* p, const ctr_batch* b, int64_t cl, double*
   }
   for (int a = 0; a < nd; ++a) { origin[a] = c.origin[a]; wshape[a] = c.wshape[a]; }
   *P_out = P;
-  free(A); free(fmax); free(coords);
+  free(A); free(fmax); free(coords); free(c.fwin);
   return c.L.nv;
 }
 
@@ -1122,6 +1219,8 @@ int ctro_hessian(const ctr_problem* p, const ctr_batch* b, int64_t cl, const dou
     for (int a = 0; a < nd; ++a) coords[i * nd + a] = params[i * np + 2 + a];
   if (!window(nd, b->shape, p->radius, coords, n, c.origin, c.wshape)) { free(fmax); free(coords); return -2; }
   c.mcoords = coords;
+  c.fwin = NULL;
+  make_fwin(&c);
   pack_start(&c, params, b->low + (size_t)f0 * np, b->high + (size_t)f0 * np, vect, lo, hi);
   if (v_in) memcpy(vect, v_in, sizeof(double) * c.L.nv);
   {
@@ -1135,6 +1234,6 @@ int ctro_hessian(const ctr_problem* p, const ctr_batch* b, int64_t cl, const dou
     for (int i = 0; i < nv * nv; ++i) hess[i] = 2. * (A[i] + Q[i]) / (double)P / norm;
     free(A); free(Q);
   }
-  free(fmax); free(coords);
+  free(fmax); free(coords); free(c.fwin);
   return c.L.nv;
 }

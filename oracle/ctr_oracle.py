@@ -122,3 +122,27 @@ def hessian(problem, batch, cluster, v_in=None, exact=True):
     if nv < 0:
         raise ValueError("ctro_hessian failed (%d)" % nv)
     return H.reshape(-1)[:nv * nv].reshape(nv, nv).copy()
+
+
+def gaussian_kernel(sigma):
+    """The restated trackpy.masks.gaussian_kernel(sigma, 4) of the oracle (parity unpinned)."""
+    lib = load()
+    w = np.zeros(2 * 16 + 1 + 8)
+    lib.ctro_gaussian_kernel.argtypes = [C.c_double, C.c_void_p]
+    lib.ctro_gaussian_kernel.restype = C.c_int
+    lw = lib.ctro_gaussian_kernel(float(sigma), w.ctypes.data)
+    return w[:2 * lw + 1].copy()
+
+
+def lowpass(window_pixels, noise_size, threshold=0.):
+    """preprocessing.py:12-49 on one window (refine.py:37-40): the oracle's filter."""
+    lib = load()
+    win = np.array(window_pixels, dtype=np.float64, order='C')
+    nd = win.ndim
+    ns = np.zeros(3)
+    ns[:nd] = noise_size
+    shape = np.asarray(win.shape, dtype=np.int32)
+    lib.ctro_lowpass.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+    lib.ctro_lowpass.restype = None
+    lib.ctro_lowpass(nd, shape.ctypes.data, ns.ctypes.data, float(threshold), win.ctypes.data)
+    return win

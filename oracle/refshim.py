@@ -11,6 +11,11 @@ arithmetic is altered:
 * ``trackpy.utils.validate_tuple``: scalar -> (v,)*ndim, len-ndim iterable ->
   tuple, else ValueError (behaviour inferred from refine.py:30,285 and
   masks.py:11,53 call sites).
+* ``trackpy.masks.gaussian_kernel`` (needed by the reference's ``lowpass``,
+  preprocessing.py:43, only when ``noise_size`` is given): restated from trackpy's published
+  source (trackpy 0.3/0.4 ``masks.py``: ``lw = int(truncate*sigma + 0.5); x = arange(-lw, lw+1);
+  exp(x**2/(-2*sigma**2)) / sum``) -- PARITY UNPINNED for this one function; the correlation
+  itself is SciPy's ``correlate1d``, which is installed.
 * ``np.bool / np.int / np.float / np.Inf`` aliases (used at refine.py:49,
   masks.py:54, find_link.py:527).
 * ``masks.slice_image`` indexes with a *list* of slices (masks.py:68), an
@@ -41,6 +46,14 @@ def _validate_tuple(value, ndim):
     raise ValueError("List length should have same length as image dimensions.")
 
 
+def _gaussian_kernel(sigma, truncate=4.0):
+    "1D discretized gaussian (restated trackpy.masks.gaussian_kernel; see the module docstring)"
+    lw = int(truncate * sigma + 0.5)
+    x = np.arange(-lw, lw + 1)
+    result = np.exp(x ** 2 / (-2 * sigma ** 2))
+    return result / np.sum(result)
+
+
 def _not_available(*args, **kwargs):
     raise NotImplementedError("trackpy/pims is not installed; this code path "
                               "is outside the refine hot path")
@@ -69,7 +82,7 @@ def load():
     tp_pre.scalefactor_to_gamut = _not_available
     tp_pre.scale_to_gamut = _not_available
     tp_masks = types.ModuleType("trackpy.masks")
-    tp_masks.gaussian_kernel = _not_available
+    tp_masks.gaussian_kernel = _gaussian_kernel
     tp_masks.r_squared_mask = _not_available
     tp_masks.x_squared_masks = _not_available
     tp_masks.binary_mask = _not_available

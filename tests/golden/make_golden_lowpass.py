@@ -1,0 +1,45 @@
+"""Generate the ``lowpass_*`` fixtures: refine_leastsq with ``noise_size`` (refine.py:37-40: every
+window is lowpass-filtered before it is fitted).
+
+Run in the build container only (needs /root/reference; see oracle/refshim.py):
+
+    python tests/golden/make_golden_lowpass.py
+
+The reference's ``lowpass`` (preprocessing.py:12-49) runs as it is; its Gaussian taps come from
+``trackpy.masks.gaussian_kernel``, which is absent here and restated in oracle/refshim.py
+(parity unpinned for that one function).  Same file format as make_golden.py.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import make_golden as mg  # noqa: E402  (loads the reference through oracle/refshim.py)
+from clustertracking_amd import artificial  # noqa: E402
+
+
+def main():
+    # 2D, noisy, sigma 1 on both axes (the usual choice); features near the frame edge too
+    im, truth, p0 = artificial.random_frame((200, 240), 60, 3., 100, 12, 41, margin=8)
+    mg.save_case('lowpass_2d', mg.table(p0, 3., 90., 6., 2, True), im[None],
+                 dict(diameter=13, noise_size=1))
+    # different sigma per axis, one axis unfiltered, with a threshold that zeroes the background
+    im, truth, p0 = artificial.random_frame((160, 160), 30, 4., 160, 16, 42, margin=16)
+    mg.save_case('lowpass_2d_threshold', mg.table(p0, 4., 150., 0., 2, True), im[None],
+                 dict(diameter=17, noise_size=(0, 1.5), threshold=20))
+    # free sizes (the lowpass widens the features)
+    mg.save_case('lowpass_2d_sizevar', mg.table(p0, 4.3, 150., 8., 2, True), im[None],
+                 dict(diameter=17, noise_size=1, param_mode=dict(size='var')))
+    # 3D anisotropic
+    im, truth, p0 = artificial.random_frame((24, 56, 56), 8, (2., 4., 4.), 100, 10, 43,
+                                            margin=(5, 9, 9))
+    mg.save_case('lowpass_3d', mg.table(p0, (2., 4., 4.), 90., 5., 3, False), im[None],
+                 dict(diameter=(9, 17, 17), noise_size=(0.5, 1, 1)))
+
+
+if __name__ == '__main__':
+    main()

@@ -115,7 +115,7 @@ def test_unsupported_is_loud(oracle):
     im, truth, f0 = small_problem()
     run = _cases.oracle_runner()
     for kw in (dict(param_mode=dict(signal='global')), dict(fit_function='ring'),
-               dict(fit_function='disc'), dict(noise_size=1),
+               dict(fit_function='disc'),
                dict(fit_function=dict(params=[], func=None))):
         with pytest.raises(NotImplementedError):
             _cases.refine_leastsq(f0.copy(), im, 13, _run_batch=run, **kw)
@@ -123,6 +123,8 @@ def test_unsupported_is_loud(oracle):
     for mode, col in ((dict(size='var'), 'size_std'), (dict(signal='cluster'), 'signal_std')):
         res = _cases.refine_leastsq(f0.copy(), im, 13, compute_error=True, param_mode=mode, _run_batch=run)
         assert np.isfinite(res[col]).all() and (res[col] > 0).all()
+    with pytest.raises(ValueError):      # lowpass sigma beyond CTR_MAX_NOISE_SIZE
+        _cases.refine_leastsq(f0.copy(), im, 13, noise_size=5, _run_batch=run)
     with pytest.raises(ValueError):
         _cases.refine_leastsq(f0.copy(), im, 13, fit_function='nonsense', _run_batch=run)
     with pytest.raises(ValueError):
