@@ -34,6 +34,9 @@ def refine_leastsq_sharded(f, reader, diameter, group=None, device=None,
     (default: the world group).  ``reader`` must serve every frame this rank
     owns.  Every rank returns the full result table when ``gather`` is true
     (frame-sorted, identical on all ranks), else only its own rows.
+    Memory: a rank stacks the frames of ITS block that hold features into one host array and
+    uploads it as one block (``prepare_batch``; the reference reads frame by frame) -- shard
+    finer, or call per chunk of frames, when a rank's block does not fit host memory or HBM.
     ``device``: HIP device index of this process; default ``LOCAL_RANK`` (set by
     torch.distributed.run; the rank inside the node, not the group rank), else the current
     torch device.

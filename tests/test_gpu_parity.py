@@ -507,3 +507,96 @@ def test_device_path_is_ordered_with_torchs_default_stream(engine, cfg2_full):
     ref = clone_batch(hb)
     engine.refine_batch(prep.problem, ref)
     assert_equal(early.cpu().numpy(), ref.params_out)
+
+
+def test_two_batches_on_two_streams_of_one_engine(engine, cfg2_full):
+    """The handle owns scratch that a call uses from start to end (frame maxima = the norm of the
+    cost, work counters, side streams): two batches queued on different streams of ONE engine
+    must not race -- the second call waits for the first on the device (include/ctrefine.h)."""
+    import torch
+    from clustertracking_amd.device import DeviceBatch
+    prep, _ = cfg2_full
+    hb = prep.batch
+
+    def part(f_lo, f_hi, scale):
+        sel = np.flatnonzero((hb.frame_index >= f_lo) & (hb.frame_index < f_hi))
+        rows = np.concatenate([np.arange(hb.feat_offset[c], hb.feat_offset[c + 1]) for c in sel])
+        off = np.concatenate([[0], np.cumsum(np.diff(hb.feat_offset)[sel])]).astype(np.int32)
+        frames = hb.frames[f_lo:f_hi]
+        if scale != 1:   # another frame maximum: a norm taken from the wrong batch would show in the cost
+            frames = (frames.astype(np.uint16) * scale).astype(np.uint16)
+        par, lo_, hi_ = hb.params[rows].copy(), hb.low[rows].copy(), hb.high[rows].copy()
+        for a in (par, lo_, hi_):
+            a[:, :2] *= scale
+        return _abi.HostBatch(frames, (hb.frame_index[sel] - f_lo).astype(np.int32), off, par, lo_, hi_)
+    a, b = part(0, 96, 1), part(96, 160, 3)
+    seq_a, seq_b = clone_batch(a), clone_batch(b)
+    engine.refine_batch(prep.problem, seq_a)
+    engine.refine_batch(prep.problem, seq_b)
+    da = DeviceBatch(prep.problem, a, device=0, engine=engine)
+    db = DeviceBatch(prep.problem, b, device=0, engine=engine)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):   # back to back, no host synchronisation in between
+        da.run(stream=s1.cuda_stream)
+        db.run(stream=s2.cuda_stream)
+    torch.cuda.synchronize()
+    da.download()
+    db.download()
+    for got, want in ((a, seq_a), (b, seq_b)):
+        assert_equal(got.status, want.status)
+        assert_equal(got.cost, want.cost)
+        assert_equal(got.params_out, want.params_out)
+
+
+def test_sharded_call_over_rccl_on_two_gpus():
+    """refine_leastsq_sharded on two MI355X over RCCL (backend 'nccl'); skipped on a one-GPU box.
+    The CPU rehearsal of the same code path is tests/test_parallel_gloo.py."""
+    import socket
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    import tempfile
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out_dir = tempfile.mkdtemp()
+    mp.spawn(_rccl_worker, args=(2, port, out_dir), nprocs=2, join=True)
+    frames, f0 = _small_video()
+    single = cta.refine_leastsq(f0.copy(), cta.ArrayReader(frames), 13)
+    for rank in range(2):
+        got = pd.read_pickle(os.path.join(out_dir, 'rank%d.pkl' % rank))
+        assert list(got.columns) == list(single.columns)
+        assert_equal(got['cluster'].values, single['cluster'].values)
+        for col in single.columns:
+            assert_equal(got[col].values.astype(float), single[col].values.astype(float))
+
+
+def _small_video(n_frames=6):
+    frames, tabs = [], []
+    for t in range(n_frames):
+        im, truth, p0 = cta.artificial.random_frame((96, 112), 14 + t, 3., 100, 10, 200 + t, margin=13)
+        frames.append(im)
+        tab = pd.DataFrame(p0, columns=['y', 'x'])
+        tab['frame'] = t
+        tabs.append(tab)
+    f0 = pd.concat(tabs, ignore_index=True)
+    f0['signal'], f0['size'], f0['background'] = 90., 3., 5.
+    return np.stack(frames), f0
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    from clustertracking_amd import parallel
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['LOCAL_RANK'] = str(rank)
+    torch.cuda.set_device(rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world)
+    frames, f0 = _small_video()
+    res = parallel.refine_leastsq_sharded(f0, cta.ArrayReader(frames), 13)
+    res.to_pickle(os.path.join(out_dir, 'rank%d.pkl' % rank))
+    dist.barrier()
+    dist.destroy_process_group()

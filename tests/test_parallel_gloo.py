@@ -40,7 +40,7 @@ def _video(n_frames=5):
     return np.stack(frames), f0
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, extra=None):
     import torch.distributed as dist
     sys.path.insert(0, os.path.join(_cases.ROOT, 'oracle'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -48,22 +48,27 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     frames, f0 = _video()
     res = _cases.refine_leastsq_sharded(f0, cta.ArrayReader(frames), 13,
-                                        _run_batch=_cases.oracle_runner())
+                                        _run_batch=_cases.oracle_runner(), **(extra or {}))
     res.to_pickle(os.path.join(out_dir, 'rank%d.pkl' % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_matches_single_process(tmp_path, oracle):
+@pytest.mark.parametrize("extra", [None, dict(compute_error=True, noise_size=1, threshold=2,
+                                                  param_mode=dict(size='var'))],
+                         ids=['defaults', 'compute_error+noise_size+sizevar'])
+def test_two_rank_gloo_matches_single_process(tmp_path, oracle, extra):
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     world = 2
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), extra), nprocs=world, join=True)
     frames, f0 = _video()
     single = _cases.refine_leastsq(f0.copy(), cta.ArrayReader(frames), 13,
-                                _run_batch=_cases.oracle_runner())
+                                _run_batch=_cases.oracle_runner(), **(extra or {}))
+    if extra:
+        assert 'size_std' in single and 'x_std' in single
     for rank in range(world):
         got = pd.read_pickle(os.path.join(str(tmp_path), 'rank%d.pkl' % rank))
         assert_equal(np.asarray(got.index), np.asarray(single.index))

@@ -30,6 +30,8 @@ if len(sys.argv) > 3:   # only the slow clusters: every block alone on its CU
 rows = np.concatenate([np.arange(hb.feat_offset[c], hb.feat_offset[c + 1]) for c in sel])
 off = np.concatenate([[0], np.cumsum(sz[sel])])
 sub = _abi.HostBatch(hb.frames, hb.frame_index[sel], off, hb.params[rows], hb.low[rows], hb.high[rows])
+if os.environ.get('THROUGHPUT'):
+    prep.problem.flags |= _abi.FLAG_THROUGHPUT
 eng = _lib.default_engine(0)
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * 16)()
