@@ -1159,7 +1159,9 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
                 Hp[e] = h + hs;
               }
               wsync();
+              STAMP(12);
               ok_a = chol_factor_w(Hp, dl, nf, lane);  // dl doubles as 1/diag until the step is built
+              STAMP(13);
               if (ok_a) {
                 for (int a = lane; a < nf; a += WAVE) {
                   w[a] = Mp[tri(fr[a] + 1)];
@@ -1167,6 +1169,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
                 }
                 wsync();
                 chol_solve_w(Hp, dl, nf, w, 1, 0, lane);
+                STAMP(14);
                 if (m) {
                   chol_solve_w(Hp, dl, nf, Y, m, LDC, lane);
                   // tangent step, range-space form: (C H^-1 C^T) mult = -C H^-1 g, so that C d = 0

@@ -39,10 +39,11 @@ eng.refine_batch(prep.problem, sub)
 lib.ctr_debug_stamps(buf, 1)
 eng.refine_batch(prep.problem, sub)
 lib.ctr_debug_stamps(buf, 0)
-tot = sum(buf[:12])
+tot = sum(buf[:15])
 names = ['eval+park', 'barrier1', 'combine+accept', 'active set', 'solve', 'step/pred', 'round/fpar', 'barrier2']
 print('clusters', len(sel), 'iterations', int(sub.n_iter.sum()), 'max', int(sub.n_iter.max()))
-names += ['(s8) solve prologue', '(s9) factor+solve', '(s10) projected step', '(s11) model decrease']
-for n, v in zip(names, list(buf[:8]) + list(buf[8:12])):
+names += ['(s8) solve prologue', '(s9) factor+solve', '(s10) projected step', '(s11) model decrease',
+          '(s12) build H (LDS path)', '(s13) factor (LDS path)', '(s14) substitutions (LDS path)']
+for n, v in zip(names, list(buf[:8]) + list(buf[8:15])):
     print('%-16s %12d cycles  %5.1f %%   %8.0f cycles/iteration' % (n, v, 100. * v / tot, v / sub.n_iter.sum()))
 print('total cycles/iteration %.0f' % (tot / sub.n_iter.sum()))
