@@ -103,8 +103,8 @@ struct ctr_handle {
   KernelInfo lp_cons[2][2][2];    // ... for constrained clusters, nt = 1, 2
   bool lp_attr[2][2][MAXNT] = {};
   bool lp_cons_attr[2][2][2] = {};
-  KernelInfo large[2][2];         // refine_large_kernel<ndim, iso>
-  bool large_attr[2][2] = {};
+  KernelInfo large[2][2][2];      // refine_large_kernel<ndim, iso, lowpass>
+  bool large_attr[2][2][2] = {};
   hipEvent_t ev_done = nullptr;   // end of the last ctr_refine_batch_device call of this handle
   hipStream_t side[NSIDE] = {};
   hipEvent_t ev_fork = nullptr, ev_gate = nullptr, ev_order = nullptr, ev_join[NSIDE] = {};
@@ -291,7 +291,8 @@ int ctr_create(ctr_handle** out, int device) {
       h->small_bulk2[di][ii] = ctr_small_kernel(2 + di, 2, ii, 16);
       h->small_table[di][ii][0] = ctr_small_kernel(2 + di, 1, ii, 8);
       h->small_table[di][ii][1] = ctr_small_kernel(2 + di, 2, ii, 64);
-      h->large[di][ii] = ctr_large_kernel(2 + di, ii);
+      h->large[di][ii][0] = ctr_large_kernel(2 + di, ii, 0);
+      h->large[di][ii][1] = ctr_large_kernel(2 + di, ii, 1);
       for (int nt = 1; nt <= MAXNT; ++nt) {
         const KernelInfo a = di == 0 ? ctr_block_kernel_2d(ii, nt, 0, 0) : ctr_block_kernel_3d(ii, nt, 0, 0);
         const KernelInfo t = di == 0 ? ctr_block_kernel_2d(ii, nt, 1, 0) : ctr_block_kernel_3d(ii, nt, 1, 0);
@@ -376,7 +377,7 @@ int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
     }
     if (bin == BIN_LARGE) {
       // the large kernel's 16-column row: [r, shared.., own.., r_o, shared_o..]
-      if (npf < 1 || 2 + 2 * nsh + npf > 16 || plan->lowpass) bin = BIN_TOO_LARGE;
+      if (npf < 1 || 2 + 2 * nsh + npf > 16) bin = BIN_TOO_LARGE;
       else {
         ws_off[(size_t)c] = ws_total;
         ws_total += large_ws((int)n, npf, nsh).total;
@@ -567,10 +568,11 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
   if (plan->bin_count[BIN_LARGE] > 0) {
     // one 1024-thread workgroup per cluster, all of a CU's LDS: first in the queue
     const int64_t cnt = plan->bin_count[BIN_LARGE];
-    const KernelInfo& ki = h->large[di][ii];
-    if (!h->large_attr[di][ii]) {
+    const int lpi = plan->lowpass ? 1 : 0;
+    const KernelInfo& ki = h->large[di][ii][lpi];
+    if (!h->large_attr[di][ii][lpi]) {
       HIP_TRY(h, hipFuncSetAttribute(ki.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ki.smem));
-      h->large_attr[di][ii] = true;
+      h->large_attr[di][ii][lpi] = true;
     }
     k.order = ord + plan->bin_begin[BIN_LARGE];
     k.n_bin = (int32_t)cnt;

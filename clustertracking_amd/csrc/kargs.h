@@ -90,6 +90,6 @@ KernelInfo ctr_block_kernel_3d(int iso, int nt, int throughput, int cons);
 KernelInfo ctr_block_kernel_lp(int ndim, int iso, int nt, int cons);
 // refine_small_kernel<ND, NF, ISO, SG>(KArgs, int* counter); nullptr if not instantiated
 const void* ctr_small_kernel(int ndim, int nf, int iso, int sg);
-KernelInfo ctr_large_kernel(int ndim, int iso);
+KernelInfo ctr_large_kernel(int ndim, int iso, int lp);   // lp: with the lowpass of the window
 
 #endif  // CTREFINE_KARGS_H

@@ -70,7 +70,8 @@ __device__ __forceinline__ bool wg_any(bool x, double* red, int lane, int wave) 
 // solves, [1] conjugate-gradient iterations, [2] pixel passes
 __device__ unsigned long long g_large_dbg[8];   // [4] ticks (100 MHz) in pixel passes, [5] in solves
 
-template <int ND, bool ISO>
+// LP: with the lowpass of the window (ctr_problem.noise_size; device_common.h:lowpass_pixel)
+template <int ND, bool ISO, bool LP = false>
 __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double* __restrict__ ws_base,
                                                           const long long* __restrict__ ws_off) {
   constexpr int NP = 2 + ND + (ISO ? 1 : ND);
@@ -336,7 +337,11 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         {
           // (all lanes run the neighbour loop -- v_readlane must not sit in divergent control
           //  flow: a spilled source register is reloaded for the active lanes only)
-          const double pix = in_i ? load_pixel(frame, k.frame_dtype, offp) : 0.;
+          double pix = 0.;
+          if (in_i) {
+            if constexpr (LP) pix = lowpass_pixel<ND>(frame, k.frame_dtype, fshape, origin, wshape, idx, k.lp_w, k.lp_half, k.prob.threshold);
+            else pix = load_pixel(frame, k.frame_dtype, offp);
+          }
           double res = pix - bgv;
           bool owner = true;
           double shared[CTR_MAX_PARAMS], down[1 + ND + NSZ];
@@ -495,7 +500,9 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
 #pragma unroll
           for (int c2 = 0; c2 < 16; ++c2) row[c2] = 0.;
           if (both) {
-            const double pix = load_pixel(frame, k.frame_dtype, offp);
+            double pix;
+            if constexpr (LP) pix = lowpass_pixel<ND>(frame, k.frame_dtype, fshape, origin, wshape, idx, k.lp_w, k.lp_half, k.prob.threshold);
+            else pix = load_pixel(frame, k.frame_dtype, offp);
             if (pix == pix) {   // (a NaN pixel of the image contributes nothing)
 #pragma unroll
               for (int side = 0; side < 2; ++side) {

@@ -10,17 +10,21 @@ namespace {
 #include "block_kernel.h"   // LayoutB, wsync
 #include "large_kernel.h"
 
-template <int ND, bool ISO>
+template <int ND, bool ISO, bool LP>
 KernelInfo one() {
   static_assert(SmemL::bytes <= 160 * 1024, "LDS budget of one CU");
-  return KernelInfo{(const void*)refine_large_kernel<ND, ISO>, SmemL::bytes, LT};
+  return KernelInfo{(const void*)refine_large_kernel<ND, ISO, LP>, SmemL::bytes, LT};
 }
 
 }  // namespace
 
-KernelInfo ctr_large_kernel(int ndim, int iso) {
-  if (ndim == 2) return iso ? one<2, true>() : one<2, false>();
-  return iso ? one<3, true>() : one<3, false>();
+KernelInfo ctr_large_kernel(int ndim, int iso, int lp) {
+  if (lp) {
+    if (ndim == 2) return iso ? one<2, true, true>() : one<2, false, true>();
+    return iso ? one<3, true, true>() : one<3, false, true>();
+  }
+  if (ndim == 2) return iso ? one<2, true, false>() : one<2, false, false>();
+  return iso ? one<3, true, false>() : one<3, false, false>();
 }
 
 // diagnostic, not part of include/ctrefine.h: totals since the last reset

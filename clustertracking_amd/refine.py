@@ -215,8 +215,7 @@ def refine_leastsq(f, reader, diameter, separation=None, fit_function='gauss',
     * ``fit_function`` other than ``'gauss'`` and ``param_mode`` value
       ``'global'`` raise ``NotImplementedError`` (there is no CPU
       fallback to hand them to).
-    * ``noise_size`` (the lowpass of every window, refine.py:37-40) up to sigma 4;
-      clusters of more than 64 features get ``cost = NaN`` with it.
+    * ``noise_size`` (the lowpass of every window, refine.py:37-40) up to sigma 4.
     * ``compute_error``: the ``'<param>_std'`` columns come from the exact second
       derivatives of the objective (the reference differentiates numerically with
       numdifftools), for every ``param_mode``; clusters of more than 64 features or 127

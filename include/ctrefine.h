@@ -112,8 +112,7 @@ typedef struct ctr_problem {
                                       sigma truncated at 4 sigma (preprocessing.py:12-49), zero
                                       beyond the WINDOW edges, before it is fitted; 0 = that axis
                                       is not filtered, all 0 = no lowpass.  At most
-                                      CTR_MAX_NOISE_SIZE; clusters of more than 64 features or 127
-                                      variables get CTR_STATUS_TOO_LARGE with a lowpass. */
+                                      CTR_MAX_NOISE_SIZE. */
 } ctr_problem;
 
 /* The data of one batch.  All arrays C-contiguous.  For ctr_refine_batch the
