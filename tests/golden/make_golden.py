@@ -122,7 +122,7 @@ def intermediates(f0, frames, call, n_clusters=6):
             continue
         sub, mesh, masks = ct_refine.prepare_subimage(coords, image, radius, call.get('noise_size'),
                                                       call.get('threshold'))
-        norm = float(image.max()) ** 2 / 100000.
+        norm = float(image.max()) ** 2 / float(call.get('residual_factor', 100000.))
         residual, jacobian = ff.get_residual([sub], [mesh], [masks], params, None, norm)
         vect = vect_from_params(params, ff.modes, None, operation=np.mean)
         with warnings.catch_warnings():

@@ -33,10 +33,12 @@ for seed in [int(x) for x in sys.argv[1].split(',')]:
         fa, fb = np.isfinite(b.params_std[rows]), np.isfinite(ref.params_std[rows])
         both = fa & fb
         rel = (np.abs(b.params_std[rows] - ref.params_std[rows])[both] / np.abs(ref.params_std[rows][both])).max() if both.any() else 0.
-        flag = b.status[c] != ref.status[c] or (fa != fb).any() or rel > 1e-4
+        nd_ = im.ndim
+        dpos = np.abs(b.params_out[rows][:, 2:2 + nd_] - ref.params_out[rows][:, 2:2 + nd_]).max()
+        flag = b.status[c] != ref.status[c] or (fa != fb).any() or rel > 1e-4 or dpos > 1e-6
         if flag:
             print(' cluster', c, 'n', sz[c], 'status', b.status[c], ref.status[c], 'iters', b.n_iter[c], ref.n_iter[c], 'rounds', b.n_rounds[c], ref.n_rounds[c],
-                  'cost', b.cost[c], ref.cost[c], 'std finite', fa.sum(), fb.sum(), 'rel', rel)
-            if sz[c] <= 3:
+                  'cost', b.cost[c], ref.cost[c], 'std finite', fa.sum(), fb.sum(), 'rel', rel, 'dpos %.2e' % dpos)
+            if sz[c] <= 4:
                 print('  engine std', b.params_std[rows]); print('  oracle std', ref.params_std[rows])
                 print('  engine out', b.params_out[rows]); print('  oracle out', ref.params_out[rows])
