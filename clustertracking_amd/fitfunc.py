@@ -121,13 +121,34 @@ class FitFunctions(object):
         shared parameters, :554-557) happens inside the engine."""
         b_abs, b_diff, b_rel = templates
         params = np.asarray(params, dtype=np.float64)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            # np.nanmax([a, b], axis=0) == np.fmax(a, b) (NaN only where both are NaN)
-            low = np.fmax(params - b_diff[0], params * (1 - b_rel[0]))
-            low = np.fmax(low, b_abs[0])
-            low[np.isnan(low)] = -np.inf
-            high = np.fmin(params + b_diff[1], params * (1 + b_rel[1]))
-            high = np.fmin(high, b_abs[1])
-            high[np.isnan(high)] = np.inf
+        n, npar = params.shape
+        low = np.full((n, npar), -np.inf)
+        high = np.full((n, npar), np.inf)
+        # column by column, only the terms whose template is set (NaN = none):
+        # np.nanmax([p - diff, p * (1 - rel), abs], axis=0) of the reference, -inf where all are NaN
+        for k in range(npar):
+            p = params[:, k]
+            lo_terms, hi_terms = [], []
+            if not np.isnan(b_diff[0][k]):
+                lo_terms.append(p - b_diff[0][k])
+            if not np.isnan(b_rel[0][k]):
+                lo_terms.append(p * (1 - b_rel[0][k]))
+            if not np.isnan(b_diff[1][k]):
+                hi_terms.append(p + b_diff[1][k])
+            if not np.isnan(b_rel[1][k]):
+                hi_terms.append(p * (1 + b_rel[1][k]))
+            for terms, out, absb, red in ((lo_terms, low, b_abs[0][k], np.fmax), (hi_terms, high, b_abs[1][k], np.fmin)):
+                col = None
+                for t in terms:
+                    col = t if col is None else red(col, t)
+                if col is None:
+                    if not np.isnan(absb):
+                        out[:, k] = absb
+                    continue
+                if not np.isnan(absb):
+                    col = red(col, absb)
+                nanmask = np.isnan(col)          # a NaN parameter: no bound from it
+                if nanmask.any():
+                    col = np.where(nanmask, -np.inf if out is low else np.inf, col)
+                out[:, k] = col
         return low, high

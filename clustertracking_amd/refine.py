@@ -109,7 +109,14 @@ def prepare_batch(f, reader, diameter, separation=None, fit_function='gauss',
     # groupby([t_column, 'cluster']) order, rows keep their order inside a group
     frame_vals = f[t_column].values
     cluster_vals = f['cluster'].values
-    order = np.lexsort((cluster_vals, frame_vals))
+    if len(frame_vals) and np.issubdtype(frame_vals.dtype, np.integer) and \
+            np.issubdtype(cluster_vals.dtype, np.integer) and frame_vals.min() >= 0 and cluster_vals.min() >= 0 \
+            and (int(frame_vals.max()) + 1) * (int(cluster_vals.max()) + 1) < 2 ** 62:
+        # one stable sort of a combined key (the same order as lexsort, at half its cost)
+        key = frame_vals.astype(np.int64) * (int(cluster_vals.max()) + 1) + cluster_vals
+        order = np.argsort(key, kind='stable')
+    else:
+        order = np.lexsort((cluster_vals, frame_vals))
     fr_s, cl_s = frame_vals[order], cluster_vals[order]
     n_rows = len(order)
     new = np.ones(n_rows, dtype=bool)
@@ -152,8 +159,8 @@ def prepare_batch(f, reader, diameter, separation=None, fit_function='gauss',
                 continue
             lo_k, hi_k = batch.low[:, k], batch.high[:, k]
             if m != 1:  # shared: loosest bound over the cluster (fitfunc.py:554-557)
-                lo_k = np.repeat(np.minimum.reduceat(lo_k, starts), n_per)
-                hi_k = np.repeat(np.maximum.reduceat(hi_k, starts), n_per)
+                lo_k = np.minimum.reduceat(lo_k, starts)
+                hi_k = np.maximum.reduceat(hi_k, starts)
             if np.any(lo_k > hi_k):
                 raise ValueError("SLSQP Error: the lower bound exceeds the "
                                  "upper bound (parameter %r)" % ff.params[k])
