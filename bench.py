@@ -55,15 +55,66 @@ def parse():
                          "(ctr_draw_frames_device; the Poisson noise is then the engine's own generator, "
                          "not NumPy's: same statistics, other bytes)")
     ap.add_argument('--gather', default='step', choices=['step', 'final'],
-                    help="N > 1: gather the result rows of EVERY step on rank 0 (default; issued from the "
-                         "host as steps finish, ctr_query_done, so that no stream sits in a device-side "
-                         "wait) or only those of the last step")
+                    help="N > 1: the result rows of EVERY step reach rank 0 (default) or only those of the "
+                         "last step")
+    ap.add_argument('--transport', default='ipc', choices=['ipc', 'rccl'],
+                    help="--gather step: 'ipc' (default) = every engine writes its rows straight into its "
+                         "part of rank 0's IPC-mapped inbox (peer stores over xGMI from the engine's last "
+                         "kernel, ctr_batch.result_rows / done_flag: no collective per step; falls back to "
+                         "'rccl' when the inbox cannot be mapped); 'rccl' = an asynchronous gather per step, "
+                         "issued from the host as steps finish (ctr_query_done)")
     ap.add_argument('--single-device', action='store_true',
                     help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+
+
+def open_inbox(torch, dist, rank, world, local_rank, nfl, pad_rows, width, coll_dev):
+    """Rank 0 allocates the inbox and the step counters, every other rank maps them through
+    torch's CUDA IPC (dmabuf handles; HSA_ENABLE_IPC_MODE_LEGACY=0) and proves with a store that
+    it can write there.  Returns (ok on every rank, inbox, seq); ok False -> the caller falls back
+    to the RCCL gather."""
+    from torch.multiprocessing import reductions
+    ok, inbox, seq, payload = True, None, None, [None]
+    try:
+        if os.environ.get('CTR_BENCH_NO_IPC'):     # (test switch: exercise the fallback)
+            raise RuntimeError("CTR_BENCH_NO_IPC is set")
+        if rank == 0:
+            inbox = torch.zeros((world, nfl, max(pad_rows, 1), width), dtype=torch.float64, device='cuda')
+            seq = torch.zeros((world, nfl), dtype=torch.int64, device='cuda')
+            torch.cuda.synchronize()
+            payload = [(reductions.reduce_tensor(inbox), reductions.reduce_tensor(seq))]
+    except Exception as e:   # noqa: BLE001 (anything here means: no inbox)
+        sys.stderr.write("rank 0: cannot export the inbox (%r)\n" % (e,))
+        ok = False
+    dist.broadcast_object_list(payload, src=0)
+    if rank != 0:
+        try:
+            (f1, a1), (f2, a2) = payload[0]
+            inbox, seq = f1(*a1), f2(*a2)
+            seq[rank].fill_(-1)                      # a peer store into rank 0's memory
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001
+            sys.stderr.write("rank %d: cannot map rank 0's inbox (%r)\n" % (rank, e))
+            ok = False
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=coll_dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    ok = bool(flag.item())
+    if ok:
+        dist.barrier()
+        if rank == 0:
+            torch.cuda.synchronize()
+            ok0 = bool((seq[1:] == -1).all())
+            flag = torch.tensor([1 if ok0 else 0], dtype=torch.int64, device=coll_dev)
+        else:
+            flag = torch.tensor([1], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+    if not ok and rank == 0:
+        sys.stderr.write("bench: no IPC inbox, falling back to --transport rccl\n")
+    return ok, inbox, seq
 
 
 def cpu_baseline(problem, host_batch):
@@ -133,11 +184,20 @@ def main():
         local_rank = 0
     multi = world > 1 or args.rehearse_collectives   # the exchange code path is active
     torch.cuda.set_device(local_rank)
-    coll_dev = 'cuda' if args.backend == 'nccl' else 'cpu'   # where collective buffers live
+    # --transport ipc (default): the rows travel as peer stores, so the timed region needs no
+    # collective at all; its control plane (row counts, barriers, the max over ranks) runs over
+    # gloo, and RCCL is brought up AFTER the timed region, where it gathers the last step's rows
+    # once more and must reproduce the inbox (rccl_cross_check).  An RCCL communicator that merely
+    # exists during the timed region costs 12-18 % of the throughput on this workload (its streams
+    # shift the mapping of the engines' 40 streams onto the 20 hardware queues; measured with one
+    # rank: 47 -> 40 M fits/s) -- the rccl transport and --gather final pay that.
+    ipc_plan = multi and args.gather == 'step' and args.transport == 'ipc'
+    ctrl_backend = 'gloo' if (ipc_plan or args.backend == 'gloo') else 'nccl'
+    coll_dev = 'cuda' if ctrl_backend == 'nccl' else 'cpu'   # where collective buffers live
     if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        if args.backend == 'nccl':
+        if ctrl_backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world,
                                     device_id=torch.device('cuda', local_rank))
         else:
@@ -191,8 +251,24 @@ def main():
         cnt_t = [torch.zeros(1, dtype=torch.int64, device=coll_dev) for _ in range(world)]
         dist.all_gather(cnt_t, torch.tensor([prep.batch.n_features], dtype=torch.int64, device=coll_dev))
         pad_rows = max(int(c.item()) for c in cnt_t)
-    dbs = [DeviceBatch(prep.problem, prep.batch, device=local_rank, engine=e, result_rows=pad_rows)
-           for e in engines]
+    # --transport ipc: rank 0 owns inbox[world, in flight, pad_rows, n_params + 1] and
+    # seq[world, in flight]; every rank maps them (torch's CUDA IPC: hipIpcOpenMemHandle) and hands
+    # its engines their slice as result_rows / done_flag
+    inbox = seq = None
+    use_ipc = False
+    data_group, data_dev = None, coll_dev        # where the RCCL / gloo gathers of rows run
+    if ipc_plan:
+        use_ipc, inbox, seq = open_inbox(torch, dist, rank, world, local_rank, nfl, pad_rows,
+                                         prep.batch.params.shape[1] + 1, coll_dev)
+        if not use_ipc and args.backend == 'nccl':
+            data_group, data_dev = dist.new_group(backend='nccl'), 'cuda'   # the rccl transport after all
+    dbs = []
+    for j, e in enumerate(engines):
+        if use_ipc:
+            dbs.append(DeviceBatch(prep.problem, prep.batch, device=local_rank, engine=e,
+                                   result_rows=inbox[rank, j], done_flag=seq[rank, j:j + 1]))
+        else:
+            dbs.append(DeviceBatch(prep.problem, prep.batch, device=local_rank, engine=e, result_rows=pad_rows))
     db = dbs[0]
     n_fits = prep.batch.n_clusters
     n_feat = prep.batch.n_features
@@ -220,12 +296,12 @@ def main():
         counts = [int(c.item()) for c in counts]
         width = prep.batch.params.shape[1] + 1
         pad = max(counts)
-        send = torch.zeros((pad, width), dtype=torch.float64, device=coll_dev)
+        send = torch.zeros((pad, width), dtype=torch.float64, device=data_dev)
         if rank == 0:
-            gather_buf = [torch.empty((pad, width), dtype=torch.float64, device=coll_dev)
+            gather_buf = [torch.empty((pad, width), dtype=torch.float64, device=data_dev)
                           for _ in range(world)]
-            gather_bufs = [[torch.empty((pad, width), dtype=torch.float64, device=coll_dev)
-                            for _ in range(world)] for _ in range(nfl)]
+            gather_bufs = [[torch.empty((pad, width), dtype=torch.float64, device=data_dev)
+                            for _ in range(world)] for _ in range(nfl if not use_ipc else 0)]
         # cluster of every feature row, resident on the device: cost[row_cluster] = cost per row
         row_cluster = torch.from_numpy(np.repeat(np.arange(n_fits, dtype=np.int64),
                                                  np.diff(prep.batch.feat_offset))).to(db.device)
@@ -235,8 +311,9 @@ def main():
         d = dbs[slot]
         # the engine has written the rows of the result table (params | cost of the row's
         # cluster, ctr_batch.result_rows) into the slot's send block itself: nothing to pack
-        buf = d.t['result_rows'] if coll_dev == 'cuda' else d.t['result_rows'].cpu()
-        slot_work[slot] = dist.gather(buf, gather_bufs[slot] if rank == 0 else None, dst=0, async_op=True)
+        buf = d.t['result_rows'] if data_dev == 'cuda' else d.t['result_rows'].cpu()
+        slot_work[slot] = dist.gather(buf, gather_bufs[slot] if rank == 0 else None, dst=0, async_op=True,
+                                      group=data_group)
 
     def poll(block_slot=None):
         """hand on the oldest finished steps; with block_slot, everything up to that slot"""
@@ -251,7 +328,7 @@ def main():
             if slot == block_slot:
                 block_slot = None
 
-    per_step_gather = multi and args.gather == 'step'
+    per_step_gather = multi and args.gather == 'step' and not use_ipc
 
     def step():
         slot = step_no[0] % nfl
@@ -263,6 +340,8 @@ def main():
             if slot_work[slot] is not None:
                 slot_work[slot].wait()                  # the gather that reads its send block (long done)
                 d.engine.engine_wait_stream(0)
+        if use_ipc:
+            d.struct.done_value = step_no[0]            # rank 0 sees seq[rank, slot] = number of the step
         d.engine.refine_batch_device(d.plan, d.struct, 0)   # the engine's own stream
         if per_step_gather:
             pending.append(slot)
@@ -278,13 +357,13 @@ def main():
     def final_gather():
         d = dbs[(step_no[0] - 1) % nfl]                 # the batch of the last step
         d.engine.stream_wait_engine(0)                  # torch's stream waits for that engine
-        if coll_dev == 'cuda':
+        if data_dev == 'cuda':
             send[:n_feat, :width - 1].copy_(d.t['params_out'])
             send[:n_feat, width - 1].copy_(d.t['cost'][row_cluster])
         else:                                           # gloo (rehearsal): through host memory
             send[:n_feat, :width - 1].copy_(d.t['params_out'].cpu())
             send[:n_feat, width - 1].copy_(d.t['cost'][row_cluster].cpu())
-        dist.gather(send, gather_buf, dst=0)
+        dist.gather(send, gather_buf, dst=0, group=data_group)
 
     def fence():
         torch.cuda.synchronize()
@@ -298,7 +377,7 @@ def main():
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    if multi:
+    if multi and not use_ipc:
         flush_gathers()
         final_gather()      # (the first gather sets up the point-to-point channels)
     fence()
@@ -308,9 +387,9 @@ def main():
         step()
     if per_step_gather:
         flush_gathers()
-    elif multi:
+    elif multi and not use_ipc:
         final_gather()
-    fence()
+    fence()                 # (--transport ipc: the rows are in rank 0's inbox once every rank's engines are done)
     elapsed = time.perf_counter() - t0
     # kernel durations of ONE batch running alone, default scheduling (no throughput flag):
     # HIP events recorded on the launch stream inside the library
@@ -333,12 +412,40 @@ def main():
     if multi and rank == 0:
         # what arrived in the last gather: rank 0's own rows must be its results, every other
         # rank's rows finite positions inside its frames
-        last = gather_bufs[(step_no[0] - 1) % nfl] if per_step_gather else gather_buf
+        if use_ipc:
+            # the inbox: every rank's slot of the last step carries that step's number, rank 0's
+            # rows are its results, the others' rows finite positions
+            slot_l = (step_no[0] - 1) % nfl
+            last = [inbox[r, slot_l] for r in range(world)]
+            seq_ok = bool((seq[:, slot_l] == step_no[0]).all())
+        else:
+            last = gather_bufs[(step_no[0] - 1) % nfl] if per_step_gather else gather_buf
+            seq_ok = True
         own = last[0][:n_feat, :width - 1].to(db.device)
-        gather_ok = bool(torch.equal(own, db.t['params_out']))
+        gather_ok = seq_ok and bool(torch.equal(own, db.t['params_out']))
         for r in range(1, world):
             rows = last[r][:counts[r], 2:4]
             gather_ok = gather_ok and bool(torch.isfinite(rows).all()) and bool((rows > -20).all())
+
+    # --transport ipc: RCCL comes up only now, outside the timed region, and gathers the rows of
+    # the last step once more over xGMI: what it delivers must be what the inbox holds
+    rccl_check = None
+    if use_ipc and args.backend == 'nccl':
+        try:
+            g_rccl = dist.new_group(backend='nccl')
+            d_last = dbs[(step_no[0] - 1) % nfl]
+            send_c = torch.zeros((pad, width), dtype=torch.float64, device='cuda')
+            send_c[:n_feat, :width - 1].copy_(d_last.t['params_out'])
+            send_c[:n_feat, width - 1].copy_(d_last.t['cost'][row_cluster])
+            bufs = [torch.empty_like(send_c) for _ in range(world)] if rank == 0 else None
+            dist.gather(send_c, bufs, dst=0, group=g_rccl)
+            torch.cuda.synchronize()
+            if rank == 0:
+                slot_l = (step_no[0] - 1) % nfl
+                rccl_check = all(bool(torch.equal(bufs[r][:counts[r]], inbox[r, slot_l][:counts[r]]))
+                                 for r in range(world))
+        except Exception as e:   # noqa: BLE001 (reported in the bench line, the measurement stands)
+            rccl_check = "failed: %r" % (e,)
 
     t_all = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
     fits_all = torch.tensor([float(n_fits)], dtype=torch.float64, device=coll_dev)
@@ -417,6 +524,10 @@ def main():
             **extra_info,
             "gather_checked": gather_ok,
             "gather": (args.gather if multi else None),
+            "gather_transport": (("ipc inbox on rank 0 (peer stores over xGMI, no collective per step)" if use_ipc
+                                  else "%s gather per step" % ('rccl' if data_dev == 'cuda' else 'gloo'))
+                                 if multi and args.gather == 'step' else None),
+            "rccl_cross_check": rccl_check,
             "batches_in_flight": nfl,
             "in_flight_results_identical": copies_same,
         }
@@ -531,6 +642,15 @@ def main():
                           "the engine's bounded LM in scalar C, OpenMP over clusters" % n_fits}
         print(json.dumps(result), flush=True)
     if multi:
+        if use_ipc and rank != 0:
+            # let go of rank 0's memory before rank 0 ends (torch: Note [Sharing CUDA tensors])
+            import gc
+            for d in dbs:
+                d.t.pop('result_rows', None)
+                d.done_flag = None
+            inbox = seq = None
+            gc.collect()
+            torch.cuda.ipc_collect()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_NDIM = 3
 MAX_NOISE_SIZE = 4.0
 MAX_PARAMS = 8
@@ -64,7 +64,7 @@ class Batch(C.Structure):
         ('params', C.c_void_p), ('low', C.c_void_p), ('high', C.c_void_p),
         ('params_out', C.c_void_p), ('cost', C.c_void_p), ('status', C.c_void_p),
         ('n_rounds', C.c_void_p), ('n_iter', C.c_void_p), ('params_std', C.c_void_p),
-        ('result_rows', C.c_void_p),
+        ('result_rows', C.c_void_p), ('done_flag', C.c_void_p), ('done_value', C.c_int64),
     ]
 
 

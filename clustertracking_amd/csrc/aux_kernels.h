@@ -250,4 +250,12 @@ __global__ void frame_max_decode_kernel(const unsigned long long* enc, double* o
 }
 
 
+// ctr_batch.done_flag: one store, queued behind everything else of the call
+__global__ void done_flag_kernel(int64_t* flag, int64_t value) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    __threadfence_system();
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 #endif  // CTREFINE_AUX_KERNELS_H

@@ -655,6 +655,8 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     hipLaunchKernelGGL(result_rows_kernel, dim3((unsigned)((b->n_features + 255) / 256)), dim3(256), 0, s,
                        b->params_out, b->cost, b->feat_offset, (int)b->n_clusters, (int)b->n_features,
                        (int)p.n_params, b->result_rows);
+  if (b->done_flag != nullptr)
+    hipLaunchKernelGGL(done_flag_kernel, dim3(1), dim3(WAVE), 0, s, b->done_flag, b->done_value);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipEventRecord(h->ev[2], s));
   HIP_TRY(h, hipEventRecord(h->ev_done, s));
@@ -869,6 +871,7 @@ int ctr_refine_batch(ctr_handle* h, const ctr_problem* p, const ctr_batch* b) {
   d.cost = d_cost; d.status = d_status; d.n_rounds = d_rounds; d.n_iter = d_iter;
   d.params_std = d_std;
   d.result_rows = nullptr;   // (the host-buffer call returns the tables themselves)
+  d.done_flag = nullptr;
   ctr_plan* plan = nullptr;
   rc = ctr_plan_create(h, p, C, b->feat_offset, &plan);
   if (rc) return rc;

@@ -9,11 +9,15 @@ from . import _abi, _lib
 class DeviceBatch(object):
     """A HostBatch uploaded once; ``run()`` queues one pass of the hot path."""
 
-    def __init__(self, problem, host_batch, device=0, engine=None, result_rows=0):
+    def __init__(self, problem, host_batch, device=0, engine=None, result_rows=0, done_flag=None):
         """result_rows: > 0 allocates ``t['result_rows']`` with that many rows (>= the features
         of the batch; rows beyond them stay zero) of n_params + 1 columns and has the engine write
         params_out | cost-of-the-row's-cluster into it (``ctr_batch.result_rows``): the block a
-        multi-GPU pipeline gathers, padded to the same row count on every rank."""
+        multi-GPU pipeline gathers, padded to the same row count on every rank.  A float64 CUDA
+        tensor instead of a count is used as that block as it is -- e.g. this rank's part of
+        rank 0's IPC-mapped inbox, so that the rows reach rank 0 as they are written.
+        done_flag: a one-element int64 CUDA tensor (local or IPC-mapped) into which every call
+        stores ``done_value`` (set it before ``run``) when the batch is finished."""
         import torch
         self.torch = torch
         self.device = torch.device('cuda', device)
@@ -44,7 +48,13 @@ class DeviceBatch(object):
         if hb.params_std is not None:
             with torch.cuda.device(self.device):
                 self.t['params_std'] = torch.empty(hb.params.shape, dtype=torch.float64, device=self.device)
-        if result_rows:
+        if hasattr(result_rows, 'data_ptr'):
+            ext = result_rows
+            if ext.dtype != torch.float64 or not ext.is_contiguous() or ext.dim() != 2 or \
+                    ext.shape[0] < hb.n_features or ext.shape[1] != hb.params.shape[1] + 1:
+                raise ValueError("result_rows tensor must be contiguous float64 [>= n_features, n_params + 1]")
+            self.t['result_rows'] = ext
+        elif result_rows:
             if result_rows < hb.n_features:
                 raise ValueError("result_rows must hold every feature of the batch")
             with torch.cuda.device(self.device):
@@ -53,6 +63,11 @@ class DeviceBatch(object):
         b = hb.as_struct()
         for name, tensor in self.t.items():
             setattr(b, name, tensor.data_ptr())
+        self.done_flag = done_flag
+        if done_flag is not None:
+            if done_flag.dtype != torch.int64 or done_flag.numel() != 1:
+                raise ValueError("done_flag must be a one-element int64 CUDA tensor")
+            b.done_flag = done_flag.data_ptr()
         self.struct = b
         self.plan = self.engine.plan(problem, hb.feat_offset)
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CTR_ABI_VERSION 4
+#define CTR_ABI_VERSION 5
 #define CTR_MAX_NDIM 3
 #define CTR_MAX_PARAMS 8 /* background, signal, <=3 positions, <=3 sizes */
 #define CTR_MAX_VARS 127 /* optimiser variables per cluster of the on-chip kernels; larger clusters
@@ -148,7 +148,15 @@ typedef struct ctr_batch {
   double* result_rows;         /* [N, n_params + 1] or NULL: params_out and, last column, the cost of
                                   the row's cluster -- the rows of the result table (refine.py:426-427)
                                   in one block, written when the batch is done: what a pipeline sends
-                                  on (the multi-GPU gather) without another pass over the outputs */
+                                  on (the multi-GPU gather) without another pass over the outputs.
+                                  May be memory of ANOTHER device of the node that this device can
+                                  write (peer / IPC-mapped: rank 0's inbox) -- the rows then travel
+                                  over xGMI as they are written, no collective per batch */
+  int64_t* done_flag;          /* NULL, or where ctr_refine_batch_device stores done_value (one
+                                  8-byte store from a kernel of its own, queued last on the call's
+                                  stream: after every output above is written); device or peer
+                                  memory like result_rows: a consumer polls it per batch */
+  int64_t done_value;
 } ctr_batch;
 
 typedef struct ctr_handle ctr_handle;

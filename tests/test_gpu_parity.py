@@ -351,6 +351,23 @@ def test_result_rows_block_written_by_the_engine(engine):
     assert_equal(rows[:n, -1], np.repeat(hb.cost, np.diff(hb.feat_offset)))
     assert_equal(rows[n:], 0.)
     assert engine.query_done()
+    # the block and a completion flag in memory the caller owns (a slice of a larger buffer, as
+    # a rank's part of rank 0's inbox is): ctr_batch.result_rows / done_flag / done_value
+    inbox = torch.zeros((3, n + 2, hb.params_out.shape[1] + 1), dtype=torch.float64, device='cuda')
+    seq = torch.zeros(3, dtype=torch.int64, device='cuda')
+    db2 = DeviceBatch(prep.problem, prep.batch, device=0, engine=engine, result_rows=inbox[1],
+                      done_flag=seq[1:2])
+    for step in (7, 8):
+        db2.struct.done_value = step
+        db2.run()
+        torch.cuda.synchronize()
+        assert seq.tolist() == [0, step, 0]
+    got = inbox.cpu().numpy()
+    assert_equal(got[1, :n], rows[:n])
+    assert_equal(got[0], 0.)
+    assert_equal(got[2], 0.)
+    with pytest.raises(ValueError):
+        DeviceBatch(prep.problem, prep.batch, device=0, engine=engine, result_rows=inbox[1, :n - 1])
 
 
 def test_empty_batch_and_bad_descriptor(engine):
