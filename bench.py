@@ -71,50 +71,90 @@ def parse():
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 
 
-def open_inbox(torch, dist, rank, world, local_rank, nfl, pad_rows, width, coll_dev):
-    """Rank 0 allocates the inbox and the step counters, every other rank maps them through
-    torch's CUDA IPC (dmabuf handles; HSA_ENABLE_IPC_MODE_LEGACY=0) and proves with a store that
-    it can write there.  Returns (ok on every rank, inbox, seq); ok False -> the caller falls back
-    to the RCCL gather."""
-    from torch.multiprocessing import reductions
-    ok, inbox, seq, payload = True, None, None, [None]
+class Inbox(object):
+    """Rank 0's block for the result rows of every rank and step in flight, mapped by all ranks:
+    rows[world, nfl, pad_rows, width] f64, then seq[world, nfl] int64 (ctr_ipc_*, include/ctrefine.h)."""
+
+    def __init__(self, engine, base, world, nfl, pad_rows, width, owner):
+        self.engine, self.base, self.owner = engine, base, owner
+        self.world, self.nfl, self.pad_rows, self.width = world, nfl, pad_rows, width
+        self.seq_off = world * nfl * pad_rows * width * 8
+
+    @staticmethod
+    def n_bytes(world, nfl, pad_rows, width):
+        return world * nfl * pad_rows * width * 8 + world * nfl * 8
+
+    def rows_addr(self, r, slot):
+        return self.base + ((r * self.nfl + slot) * self.pad_rows) * self.width * 8
+
+    def seq_addr(self, r, slot):
+        return self.base + self.seq_off + (r * self.nfl + slot) * 8
+
+    def read_rows(self, r, slot, n):
+        return self.engine.ipc_read(self.rows_addr(r, slot), (n, self.width), np.float64)
+
+    def read_seq(self):
+        return self.engine.ipc_read(self.base + self.seq_off, (self.world, self.nfl), np.int64)
+
+    def release(self):
+        if self.base:
+            (self.engine.ipc_free if self.owner else self.engine.ipc_close)(self.base)
+            self.base = 0
+
+
+def open_inbox(torch, dist, engine, rank, world, nfl, pad_rows, width, coll_dev):
+    """Rank 0 allocates the inbox and hands its IPC handle round; every other rank maps it for
+    its own device and proves with a store FROM A KERNEL of that device that it can write there
+    (ctr_ipc_probe).  Returns (ok on every rank, Inbox); ok False -> the caller falls back to
+    the RCCL gather."""
+    ok, box, payload = True, None, [None]
+    pad_rows = max(pad_rows, 1)
     try:
         if os.environ.get('CTR_BENCH_NO_IPC'):     # (test switch: exercise the fallback)
             raise RuntimeError("CTR_BENCH_NO_IPC is set")
         if rank == 0:
-            inbox = torch.zeros((world, nfl, max(pad_rows, 1), width), dtype=torch.float64, device='cuda')
-            seq = torch.zeros((world, nfl), dtype=torch.int64, device='cuda')
-            torch.cuda.synchronize()
-            payload = [(reductions.reduce_tensor(inbox), reductions.reduce_tensor(seq))]
+            base, handle = engine.ipc_alloc(Inbox.n_bytes(world, nfl, pad_rows, width))
+            box = Inbox(engine, base, world, nfl, pad_rows, width, owner=True)
+            payload = [handle]
     except Exception as e:   # noqa: BLE001 (anything here means: no inbox)
         sys.stderr.write("rank 0: cannot export the inbox (%r)\n" % (e,))
         ok = False
     dist.broadcast_object_list(payload, src=0)
     if rank != 0:
         try:
-            (f1, a1), (f2, a2) = payload[0]
-            inbox, seq = f1(*a1), f2(*a2)
-            seq[rank].fill_(-1)                      # a peer store into rank 0's memory
-            torch.cuda.synchronize()
+            if payload[0] is None:
+                raise RuntimeError("rank 0 has no inbox")
+            box = Inbox(engine, engine.ipc_open(payload[0]), world, nfl, pad_rows, width, owner=False)
+            for slot in range(nfl):
+                engine.ipc_probe(box.seq_addr(rank, slot), -1 - rank)   # a peer store into rank 0's memory
         except Exception as e:   # noqa: BLE001
-            sys.stderr.write("rank %d: cannot map rank 0's inbox (%r)\n" % (rank, e))
+            sys.stderr.write("rank %d: cannot map or write rank 0's inbox (%r)\n" % (rank, e))
             ok = False
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=coll_dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # (also orders the probes before rank 0's look)
+    ok = bool(flag.item())
+    if ok and rank == 0:
+        seq = box.read_seq()
+        ok = all((seq[r] == -1 - r).all() for r in range(1, world))
     flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=coll_dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     ok = bool(flag.item())
-    if ok:
-        dist.barrier()
+    if not ok:
+        try:
+            if box is not None and rank != 0:
+                box.release()
+        except Exception:   # noqa: BLE001
+            pass
+        dist.barrier()          # importers first, then the owner
+        try:
+            if box is not None and rank == 0:
+                box.release()
+        except Exception:   # noqa: BLE001
+            pass
         if rank == 0:
-            torch.cuda.synchronize()
-            ok0 = bool((seq[1:] == -1).all())
-            flag = torch.tensor([1 if ok0 else 0], dtype=torch.int64, device=coll_dev)
-        else:
-            flag = torch.tensor([1], dtype=torch.int64, device=coll_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        ok = bool(flag.item())
-    if not ok and rank == 0:
-        sys.stderr.write("bench: no IPC inbox, falling back to --transport rccl\n")
-    return ok, inbox, seq
+            sys.stderr.write("bench: no IPC inbox, falling back to --transport rccl\n")
+        box = None
+    return ok, box
 
 
 def cpu_baseline(problem, host_batch):
@@ -254,19 +294,20 @@ def main():
     # --transport ipc: rank 0 owns inbox[world, in flight, pad_rows, n_params + 1] and
     # seq[world, in flight]; every rank maps them (torch's CUDA IPC: hipIpcOpenMemHandle) and hands
     # its engines their slice as result_rows / done_flag
-    inbox = seq = None
+    inbox = None
     use_ipc = False
     data_group, data_dev = None, coll_dev        # where the RCCL / gloo gathers of rows run
     if ipc_plan:
-        use_ipc, inbox, seq = open_inbox(torch, dist, rank, world, local_rank, nfl, pad_rows,
-                                         prep.batch.params.shape[1] + 1, coll_dev)
+        use_ipc, inbox = open_inbox(torch, dist, engines[0], rank, world, nfl, pad_rows,
+                                    prep.batch.params.shape[1] + 1, coll_dev)
         if not use_ipc and args.backend == 'nccl':
             data_group, data_dev = dist.new_group(backend='nccl'), 'cuda'   # the rccl transport after all
     dbs = []
     for j, e in enumerate(engines):
         if use_ipc:
             dbs.append(DeviceBatch(prep.problem, prep.batch, device=local_rank, engine=e,
-                                   result_rows=inbox[rank, j], done_flag=seq[rank, j:j + 1]))
+                                   result_rows=(inbox.rows_addr(rank, j), inbox.pad_rows),
+                                   done_flag=inbox.seq_addr(rank, j)))
         else:
             dbs.append(DeviceBatch(prep.problem, prep.batch, device=local_rank, engine=e, result_rows=pad_rows))
     db = dbs[0]
@@ -416,13 +457,13 @@ def main():
             # the inbox: every rank's slot of the last step carries that step's number, rank 0's
             # rows are its results, the others' rows finite positions
             slot_l = (step_no[0] - 1) % nfl
-            last = [inbox[r, slot_l] for r in range(world)]
-            seq_ok = bool((seq[:, slot_l] == step_no[0]).all())
+            last = [torch.from_numpy(inbox.read_rows(r, slot_l, counts[r])) for r in range(world)]
+            seq_ok = bool((inbox.read_seq()[:, slot_l] == step_no[0]).all())
         else:
             last = gather_bufs[(step_no[0] - 1) % nfl] if per_step_gather else gather_buf
             seq_ok = True
         own = last[0][:n_feat, :width - 1].to(db.device)
-        gather_ok = seq_ok and bool(torch.equal(own, db.t['params_out']))
+        gather_ok = seq_ok and bool(torch.equal(own, dbs[(step_no[0] - 1) % nfl].t['params_out']))
         for r in range(1, world):
             rows = last[r][:counts[r], 2:4]
             gather_ok = gather_ok and bool(torch.isfinite(rows).all()) and bool((rows > -20).all())
@@ -442,7 +483,8 @@ def main():
             torch.cuda.synchronize()
             if rank == 0:
                 slot_l = (step_no[0] - 1) % nfl
-                rccl_check = all(bool(torch.equal(bufs[r][:counts[r]], inbox[r, slot_l][:counts[r]]))
+                rccl_check = all(bool(np.array_equal(bufs[r][:counts[r]].cpu().numpy(),
+                                                     inbox.read_rows(r, slot_l, counts[r])))
                                  for r in range(world))
         except Exception as e:   # noqa: BLE001 (reported in the bench line, the measurement stands)
             rccl_check = "failed: %r" % (e,)
@@ -642,15 +684,14 @@ def main():
                           "the engine's bounded LM in scalar C, OpenMP over clusters" % n_fits}
         print(json.dumps(result), flush=True)
     if multi:
-        if use_ipc and rank != 0:
-            # let go of rank 0's memory before rank 0 ends (torch: Note [Sharing CUDA tensors])
-            import gc
-            for d in dbs:
-                d.t.pop('result_rows', None)
-                d.done_flag = None
-            inbox = seq = None
-            gc.collect()
-            torch.cuda.ipc_collect()
+        if use_ipc:
+            # importers unmap, then the owner frees
+            torch.cuda.synchronize()
+            if rank != 0:
+                inbox.release()
+            dist.barrier()
+            if rank == 0:
+                inbox.release()
         dist.barrier()
         dist.destroy_process_group()
 

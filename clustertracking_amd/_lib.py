@@ -18,7 +18,8 @@ EXPORTS = ('ctr_abi_version', 'ctr_create', 'ctr_destroy', 'ctr_last_error',
            'ctr_plan_create', 'ctr_plan_destroy', 'ctr_refine_batch_device',
            'ctr_frame_max_device', 'ctr_synchronize', 'ctr_last_kernel_ms',
            'ctr_find_clusters', 'ctr_engine_wait_stream', 'ctr_stream_wait_engine',
-           'ctr_draw_frames_device', 'ctr_query_done')
+           'ctr_draw_frames_device', 'ctr_query_done', 'ctr_ipc_alloc', 'ctr_ipc_open',
+           'ctr_ipc_probe', 'ctr_ipc_read', 'ctr_ipc_close', 'ctr_ipc_free')
 
 _lib = None
 _lock = threading.Lock()
@@ -106,6 +107,15 @@ def load():
         lib.ctr_draw_frames_device.restype = C.c_int
         lib.ctr_query_done.argtypes = [C.c_void_p]
         lib.ctr_query_done.restype = C.c_int
+        lib.ctr_ipc_alloc.argtypes = [C.c_void_p, C.c_int64, P(C.c_void_p), C.c_void_p]
+        lib.ctr_ipc_open.argtypes = [C.c_void_p, C.c_void_p, P(C.c_void_p)]
+        lib.ctr_ipc_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        lib.ctr_ipc_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        lib.ctr_ipc_close.argtypes = [C.c_void_p, C.c_void_p]
+        lib.ctr_ipc_free.argtypes = [C.c_void_p, C.c_void_p]
+        for fn in (lib.ctr_ipc_alloc, lib.ctr_ipc_open, lib.ctr_ipc_probe, lib.ctr_ipc_read,
+                   lib.ctr_ipc_close, lib.ctr_ipc_free):
+            fn.restype = C.c_int
         lib.ctr_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_double), P(C.c_double)]
         lib.ctr_last_kernel_ms.restype = C.c_int
         if lib.ctr_abi_version() != _abi.ABI_VERSION:
@@ -205,6 +215,37 @@ class Engine(object):
     def synchronize(self, stream=None):
         self._check(self._lib.ctr_synchronize(self._h, C.c_void_p(stream or 0)),
                     'ctr_synchronize')
+
+    # ---- the inbox of a multi-GPU pipeline (include/ctrefine.h: ctr_ipc_*) ---------------------
+    def ipc_alloc(self, n_bytes):
+        """(device pointer, 64-byte handle) of a zeroed block on this engine's device that other
+        processes can map."""
+        ptr = C.c_void_p()
+        handle = (C.c_ubyte * 64)()
+        self._check(self._lib.ctr_ipc_alloc(self._h, C.c_int64(int(n_bytes)), C.byref(ptr), handle), 'ctr_ipc_alloc')
+        return int(ptr.value), bytes(handle)
+
+    def ipc_open(self, handle):
+        ptr = C.c_void_p()
+        buf = (C.c_ubyte * 64).from_buffer_copy(handle)
+        self._check(self._lib.ctr_ipc_open(self._h, buf, C.byref(ptr)), 'ctr_ipc_open')
+        return int(ptr.value)
+
+    def ipc_probe(self, ptr, value):
+        self._check(self._lib.ctr_ipc_probe(self._h, C.c_void_p(int(ptr)), C.c_int64(int(value))), 'ctr_ipc_probe')
+
+    def ipc_read(self, ptr, shape, dtype):
+        import numpy as np
+        out = np.empty(shape, dtype=dtype)
+        self._check(self._lib.ctr_ipc_read(self._h, C.c_void_p(out.ctypes.data), C.c_void_p(int(ptr)),
+                                           C.c_int64(out.nbytes)), 'ctr_ipc_read')
+        return out
+
+    def ipc_close(self, ptr):
+        self._check(self._lib.ctr_ipc_close(self._h, C.c_void_p(int(ptr))), 'ctr_ipc_close')
+
+    def ipc_free(self, ptr):
+        self._check(self._lib.ctr_ipc_free(self._h, C.c_void_p(int(ptr))), 'ctr_ipc_free')
 
     def engine_wait_stream(self, stream=0):
         """The engine's own stream waits (on the device) for what is queued on ``stream``

@@ -666,6 +666,67 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
 
 
 
+static_assert(sizeof(hipIpcMemHandle_t) == CTR_IPC_HANDLE_BYTES, "IPC handle size");
+
+int ctr_ipc_alloc(ctr_handle* h, int64_t bytes, void** dev_ptr, unsigned char* handle_out) {
+  if (!h || !dev_ptr || !handle_out || bytes <= 0) return CTR_ERR_INVALID;
+  *dev_ptr = nullptr;
+  HIP_TRY(h, hipSetDevice(h->device));
+  void* p = nullptr;
+  if (hipMalloc(&p, (size_t)bytes) != hipSuccess) return fail(h, CTR_ERR_NOMEM, "cannot allocate the inbox");
+  hipIpcMemHandle_t ih;
+  hipError_t e = hipMemset(p, 0, (size_t)bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&ih, p);
+  if (e != hipSuccess) { (void)hipFree(p); return fail(h, CTR_ERR_DEVICE, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e)); }
+  std::memcpy(handle_out, &ih, sizeof ih);
+  *dev_ptr = p;
+  return CTR_OK;
+}
+
+int ctr_ipc_open(ctr_handle* h, const unsigned char* handle, void** dev_ptr) {
+  if (!h || !handle || !dev_ptr) return CTR_ERR_INVALID;
+  *dev_ptr = nullptr;
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipIpcMemHandle_t ih;
+  std::memcpy(&ih, handle, sizeof ih);
+  void* p = nullptr;
+  const hipError_t e = hipIpcOpenMemHandle(&p, ih, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) return fail(h, CTR_ERR_DEVICE, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+  *dev_ptr = p;
+  return CTR_OK;
+}
+
+int ctr_ipc_probe(ctr_handle* h, void* dst, int64_t value) {
+  if (!h || !dst) return CTR_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(done_flag_kernel, dim3(1), dim3(WAVE), 0, h->stream, (int64_t*)dst, value);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return CTR_OK;
+}
+
+int ctr_ipc_read(ctr_handle* h, void* dst_host, const void* src, int64_t bytes) {
+  if (!h || !dst_host || !src || bytes < 0) return CTR_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpy(dst_host, src, (size_t)bytes, hipMemcpyDeviceToHost));
+  return CTR_OK;
+}
+
+int ctr_ipc_close(ctr_handle* h, void* dev_ptr) {
+  if (!h || !dev_ptr) return CTR_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipIpcCloseMemHandle(dev_ptr));
+  return CTR_OK;
+}
+
+int ctr_ipc_free(ctr_handle* h, void* dev_ptr) {
+  if (!h || !dev_ptr) return CTR_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipFree(dev_ptr));
+  return CTR_OK;
+}
+
 int ctr_find_clusters(ctr_handle* h, int32_t ndim, const double* pos, const int32_t* frame_offset,
                       int64_t n_frames, const double* separation, int32_t* label_out, int32_t* size_out) {
   if (!h || !pos || !frame_offset || !separation || !label_out || !size_out) return CTR_ERR_INVALID;

@@ -15,9 +15,10 @@ class DeviceBatch(object):
         params_out | cost-of-the-row's-cluster into it (``ctr_batch.result_rows``): the block a
         multi-GPU pipeline gathers, padded to the same row count on every rank.  A float64 CUDA
         tensor instead of a count is used as that block as it is -- e.g. this rank's part of
-        rank 0's IPC-mapped inbox, so that the rows reach rank 0 as they are written.
-        done_flag: a one-element int64 CUDA tensor (local or IPC-mapped) into which every call
-        stores ``done_value`` (set it before ``run``) when the batch is finished."""
+        rank 0's inbox, so that the rows reach rank 0 as they are written; ``(address, rows)``
+        names such a block by its address (memory mapped with ``Engine.ipc_open``).
+        done_flag: a one-element int64 CUDA tensor, or an address, into which every call stores
+        ``done_value`` (set ``struct.done_value`` before ``run``) when the batch is finished."""
         import torch
         self.torch = torch
         self.device = torch.device('cuda', device)
@@ -48,7 +49,14 @@ class DeviceBatch(object):
         if hb.params_std is not None:
             with torch.cuda.device(self.device):
                 self.t['params_std'] = torch.empty(hb.params.shape, dtype=torch.float64, device=self.device)
-        if hasattr(result_rows, 'data_ptr'):
+        self.raw_rows = None
+        if isinstance(result_rows, tuple):
+            # (address, rows): a block this process has mapped (ctr_ipc_open) or owns (ctr_ipc_alloc)
+            addr, n_rows = result_rows
+            if int(n_rows) < hb.n_features:
+                raise ValueError("result_rows must hold every feature of the batch")
+            self.raw_rows = int(addr)
+        elif hasattr(result_rows, 'data_ptr'):
             ext = result_rows
             if ext.dtype != torch.float64 or not ext.is_contiguous() or ext.dim() != 2 or \
                     ext.shape[0] < hb.n_features or ext.shape[1] != hb.params.shape[1] + 1:
@@ -63,8 +71,12 @@ class DeviceBatch(object):
         b = hb.as_struct()
         for name, tensor in self.t.items():
             setattr(b, name, tensor.data_ptr())
+        if self.raw_rows is not None:
+            b.result_rows = self.raw_rows
         self.done_flag = done_flag
-        if done_flag is not None:
+        if isinstance(done_flag, int):
+            b.done_flag = done_flag            # an address inside a mapped block
+        elif done_flag is not None:
             if done_flag.dtype != torch.int64 or done_flag.numel() != 1:
                 raise ValueError("done_flag must be a one-element int64 CUDA tensor")
             b.done_flag = done_flag.data_ptr()

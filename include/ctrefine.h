@@ -247,6 +247,26 @@ int ctr_query_done(ctr_handle* h);
 /* Block until the work queued by the *_device calls on `hip_stream` is done. */
 int ctr_synchronize(ctr_handle* h, void* hip_stream);
 
+/* The inbox of a multi-GPU pipeline (one process per GPU): the rank that collects the result rows
+ * allocates a block on its device and exports it; every other rank maps it and passes addresses
+ * inside it as ctr_batch.result_rows / done_flag, so that the rows travel as peer stores over xGMI
+ * while they are written -- no collective per batch (bench.py:open_inbox is the worked example).
+ *   ctr_ipc_alloc: hipMalloc of `bytes` zeroed bytes on the handle's device + its IPC handle
+ *     (CTR_IPC_HANDLE_BYTES bytes, to be sent to the other processes by any means).
+ *   ctr_ipc_open: maps such a block into this process for the handle's device
+ *     (hipIpcOpenMemHandle with lazy peer access, called with that device current).
+ *   ctr_ipc_probe: stores `value` at `dst` (8 bytes) FROM A KERNEL of the handle's device and
+ *     waits for it: proves at set-up time that this device can write the mapped block.
+ *   ctr_ipc_read: copies `bytes` from device / mapped memory to the host (blocking).
+ *   ctr_ipc_close / ctr_ipc_free: unmap (importer) / release (owner, after every importer closed). */
+#define CTR_IPC_HANDLE_BYTES 64
+int ctr_ipc_alloc(ctr_handle* h, int64_t bytes, void** dev_ptr, unsigned char* handle_out);
+int ctr_ipc_open(ctr_handle* h, const unsigned char* handle, void** dev_ptr);
+int ctr_ipc_probe(ctr_handle* h, void* dst, int64_t value);
+int ctr_ipc_read(ctr_handle* h, void* dst_host, const void* src, int64_t bytes);
+int ctr_ipc_close(ctr_handle* h, void* dev_ptr);
+int ctr_ipc_free(ctr_handle* h, void* dev_ptr);
+
 /* Ordering with a caller's stream when the *_device calls run on the handle's own stream
  * (hip_stream = NULL above), without blocking the host.  `hip_stream` here is a hipStream_t
  * passed as void*; NULL means the legacy default stream (what PyTorch uses unless told

@@ -368,6 +368,27 @@ def test_result_rows_block_written_by_the_engine(engine):
     assert_equal(got[2], 0.)
     with pytest.raises(ValueError):
         DeviceBatch(prep.problem, prep.batch, device=0, engine=engine, result_rows=inbox[1, :n - 1])
+    # the same through the engine's own inbox calls (ctr_ipc_*): a block named by its address,
+    # as a rank sees the block of rank 0 that it has mapped
+    width = hb.params_out.shape[1] + 1
+    n_bytes = 2 * n * width * 8 + 2 * 8
+    base, handle = engine.ipc_alloc(n_bytes)
+    try:
+        assert len(handle) == 64
+        seq_addr = base + 2 * n * width * 8
+        engine.ipc_probe(seq_addr + 8, -5)                      # a store from a kernel
+        assert engine.ipc_read(seq_addr, (2,), np.int64).tolist() == [0, -5]
+        db3 = DeviceBatch(prep.problem, prep.batch, device=0, engine=engine,
+                          result_rows=(base + n * width * 8, n), done_flag=seq_addr)
+        db3.struct.done_value = 41
+        db3.run()
+        torch.cuda.synchronize()
+        assert engine.ipc_read(seq_addr, (2,), np.int64).tolist() == [41, -5]
+        got = engine.ipc_read(base, (2, n, width), np.float64)
+        assert_equal(got[1], rows[:n])
+        assert_equal(got[0], 0.)
+    finally:
+        engine.ipc_free(base)
 
 
 def test_empty_batch_and_bad_descriptor(engine):
