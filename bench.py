@@ -224,6 +224,14 @@ def main():
         local_rank = 0
     multi = world > 1 or args.rehearse_collectives   # the exchange code path is active
     torch.cuda.set_device(local_rank)
+    # The engines first: their 5 streams each are assigned to the hardware queues round robin in
+    # the order of creation, and with 20 queues and 8 engines that puts exactly two streams of the
+    # same role, four engines apart, on every queue.  The throughput depends on that pattern
+    # (GPU_MAX_HW_QUEUES 19 / 20 / 21 / 23 / 24: 38 / 46 / 46 / 35 / 25 M fits/s), so nothing
+    # that creates streams of its own (an RCCL communicator) may come before them.
+    from clustertracking_amd import _lib, _abi
+    nfl = max(1, args.in_flight)
+    engines = [_lib.default_engine(local_rank)] + [_lib.Engine(local_rank) for _ in range(nfl - 1)]
     # --transport ipc (default): the rows travel as peer stores, so the timed region needs no
     # collective at all; its control plane (row counts, barriers, the max over ranks) runs over
     # gloo, and RCCL is brought up AFTER the timed region, where it gathers the last step's rows
@@ -280,11 +288,8 @@ def main():
     t0 = time.perf_counter()
     prep = cta.prepare_batch(f0, reader, opts['diameter'], **extra)
     t_host_prep = time.perf_counter() - t0
-    from clustertracking_amd import _lib, _abi
-    nfl = max(1, args.in_flight)
     if nfl > 1:     # several batches in flight: machine time per cluster before one-batch latency
         prep.problem.flags |= _abi.FLAG_THROUGHPUT
-    engines = [_lib.default_engine(local_rank)] + [_lib.Engine(local_rank) for _ in range(nfl - 1)]
     pad_rows = 0
     if multi and args.gather == 'step':
         # every rank sends the same number of rows: the largest feature count of any rank
