@@ -198,16 +198,17 @@ def algorithmic_flops(problem, hb, n_iter):
 
 def main():
     args = parse()
-    # Every size class of a batch is one kernel on its own stream (5 streams per engine
-    # handle), and --in-flight batches are in flight: that needs more hardware queues than
+    # Every size class of a batch is one kernel, on one of the 4 streams of its engine
+    # handle, and --in-flight batches are in flight: that needs more hardware queues than
     # ROCm's default of 4 per process, or kernels of different streams queue up behind each
     # other.  Read by the HIP runtime when it initialises, hence set before torch is imported.
-    # (At most 20: from 24 queues on, every small kernel of the chain -- fill, frame maximum,
-    # ordering -- takes ~0.1 ms instead of ~0.02 ms on this runtime; with 8 batches in flight
-    # on 20 queues the handles share queues, which costs nothing measurable.)
-    with_collectives = int(os.environ.get('WORLD_SIZE', '1')) > 1 or args.rehearse_collectives
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', str(min(23 if with_collectives else 20,   # RCCL takes a few
-                                                       max(4, 5 * max(1, args.in_flight)))))
+    # An engine handle has 1 + 3 streams and HIP deals streams to the queues round robin: with
+    # 2 queues per batch in flight (16 for the default 8) every queue carries two streams of the
+    # same role, four handles apart.  The rate depends on that pattern -- 12 / 16 / 17 / 19 / 20 /
+    # 24 / 28 queues: 35 / 48 / 45 / 41 / 47 / 38 / 36 M fits/s -- so the SAME count is used with
+    # and without a process group (from 24 queues on, every small kernel of the chain -- fill,
+    # frame maximum, ordering -- takes ~0.1 ms instead of ~0.02 ms on this runtime).
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', str(min(20, max(4, 2 * max(1, args.in_flight)))))
     import torch
     import torch.distributed as dist
     import clustertracking_amd as cta
@@ -224,11 +225,9 @@ def main():
         local_rank = 0
     multi = world > 1 or args.rehearse_collectives   # the exchange code path is active
     torch.cuda.set_device(local_rank)
-    # The engines first: their 5 streams each are assigned to the hardware queues round robin in
-    # the order of creation, and with 20 queues and 8 engines that puts exactly two streams of the
-    # same role, four engines apart, on every queue.  The throughput depends on that pattern
-    # (GPU_MAX_HW_QUEUES 19 / 20 / 21 / 23 / 24: 38 / 46 / 46 / 35 / 25 M fits/s), so nothing
-    # that creates streams of its own (an RCCL communicator) may come before them.
+    # The engines first: their streams are dealt to the hardware queues in the order of creation
+    # (see GPU_MAX_HW_QUEUES above), so nothing that creates streams of its own (an RCCL
+    # communicator) may come before them.
     from clustertracking_amd import _lib, _abi
     nfl = max(1, args.in_flight)
     engines = [_lib.default_engine(local_rank)] + [_lib.Engine(local_rank) for _ in range(nfl - 1)]

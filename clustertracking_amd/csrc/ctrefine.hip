@@ -53,7 +53,12 @@ std::mutex g_mutex;
 constexpr int BIN_TOO_LARGE = MAXNT, BIN_SMALL1 = MAXNT + 1, BIN_SMALL2 = MAXNT + 2, BIN_LARGE = MAXNT + 3,
               BIN_CONS1 = MAXNT + 4, BIN_CONS2 = MAXNT + 5, NBINS = MAXNT + 6;
 static_assert(NBINS <= 16, "FrontArgs (aux_kernels.h) holds 16 bins");
-constexpr int NSIDE = 4;  // side streams for concurrent bin launches
+// side streams for concurrent bin launches.  Three, not more: HIP deals streams to the hardware
+// queues round robin, and with 1 + 3 streams per handle and a queue count that is a multiple of 4
+// the streams that share a queue have the same role in different handles; eight handles in flight
+// reach the same rate as with four side streams (48 M cluster-fits/s on cfg 2) over a wider range
+// of GPU_MAX_HW_QUEUES (16..22 instead of 20..22)
+constexpr int NSIDE = 3;
 constexpr int GATE_US = 20;  // head start of the block kernels over the small kernels (delay_kernel)
 
 struct ctr_plan {

@@ -47,7 +47,7 @@ def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_path(tmp_path):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, GPU_MAX_HW_QUEUES='20')
+    env = dict(os.environ)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(port),
            os.path.join(_cases.ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--single-device',
