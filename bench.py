@@ -63,6 +63,10 @@ def parse():
                          "kernel, ctr_batch.result_rows / done_flag: no collective per step; falls back to "
                          "'rccl' when the inbox cannot be mapped); 'rccl' = an asynchronous gather per step, "
                          "issued from the host as steps finish (ctr_query_done)")
+    ap.add_argument('--layout', default='auto', choices=['auto', 'default', 'tail'],
+                    help="stream layout of the engines: 'tail' = CTR_FLAG_ISOLATE_TAIL (only the kernel of the "
+                         "likely slow fits beside the main stream); 'auto' (default) times a few steps of both "
+                         "before the warm-up and keeps 'tail' where it is at least 7 %% faster")
     ap.add_argument('--single-device', action='store_true',
                     help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
@@ -420,6 +424,40 @@ def main():
     for d in dbs:
         d.engine.refine_batch_device(d.plan, d.struct, 0)
     torch.cuda.synchronize()
+    # Scheduling choice, made per rank before the warm-up (untimed): a batch that holds one fit
+    # far slower than the rest (cfg 2: two start positions on one real feature, 300+ iterations,
+    # 4 ms in the pairs kernel of every step -- 2 of the 8 shards of an 8-GPU run have one) is
+    # served better with CTR_FLAG_ISOLATE_TAIL (include/ctrefine.h); which it is shows in a few
+    # steps of each.  Results do not depend on the flag.
+    layout = 'default'
+    if nfl > 1 and args.layout != 'default':
+        import copy
+        prob_tail = copy.copy(prep.problem)
+        prob_tail.flags |= _abi.FLAG_ISOLATE_TAIL
+        plans = {'default': [d.plan for d in dbs],
+                 'tail': [d.engine.plan(prob_tail, prep.batch.feat_offset) for d in dbs]}
+        trial = {}
+        if args.layout == 'auto':
+            for name in ('default', 'tail', 'default', 'tail'):
+                for d, pl in zip(dbs, plans[name]):
+                    d.plan = pl
+                for d in dbs:                                   # (attributes, code)
+                    d.engine.refine_batch_device(d.plan, d.struct, 0)
+                torch.cuda.synchronize()
+                t_try = time.perf_counter()
+                for k_try in range(2 * nfl):
+                    d = dbs[k_try % nfl]
+                    d.engine.refine_batch_device(d.plan, d.struct, 0)
+                torch.cuda.synchronize()
+                trial[name] = min(trial.get(name, 1e9), (time.perf_counter() - t_try) / (2 * nfl))
+            layout = 'tail' if trial['tail'] < 0.93 * trial['default'] else 'default'
+        else:
+            layout = args.layout
+        for d, pl in zip(dbs, plans[layout]):
+            d.plan = pl
+        layout_info = {"layout": layout, "layout_trial_ms_per_step": {k2: v * 1e3 for k2, v in trial.items()}}
+    else:
+        layout_info = {"layout": layout}
     for _ in range(args.warmup):
         step()
     if multi and not use_ipc:
@@ -575,6 +613,7 @@ def main():
                                  if multi and args.gather == 'step' else None),
             "rccl_cross_check": rccl_check,
             "batches_in_flight": nfl,
+            **layout_info,
             "in_flight_results_identical": copies_same,
         }
         big_clusters = int(np.diff(hb.feat_offset).max()) > 127 if hb.n_clusters else False

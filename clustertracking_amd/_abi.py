@@ -40,6 +40,7 @@ STATUS_TEXT = {
 
 
 FLAG_THROUGHPUT = 1   # ctr_problem.flags (include/ctrefine.h): scheduling hint, results unchanged
+FLAG_ISOLATE_TAIL = 2  # only the kernel of the likely slow fits beside the main stream
 
 
 class Problem(C.Structure):

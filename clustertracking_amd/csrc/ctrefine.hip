@@ -526,8 +526,17 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
   HIP_TRY(h, hipEventRecord(h->ev_fork, s));
   bool used[NSIDE] = {};
   int next_side = 0;
+  // CTR_FLAG_ISOLATE_TAIL: only the tier of the likely slow fits (the 64-lane pairs kernel, the
+  // large-cluster kernel) leaves the main stream
+  const bool isolate = (p.flags & CTR_FLAG_ISOLATE_TAIL) != 0;
+  bool slow_tier = false;
   auto pick_stream = [&](bool main_stream) -> hipStream_t {
     if (main_stream) return s;
+    if (isolate) {
+      if (!slow_tier) return s;
+      if (!used[0]) { used[0] = true; (void)hipStreamWaitEvent(h->side[0], h->ev_fork, 0); }
+      return h->side[0];
+    }
     const int j = next_side++ % NSIDE;
     if (!used[j]) { used[j] = true; (void)hipStreamWaitEvent(h->side[j], h->ev_fork, 0); }
     return h->side[j];
@@ -584,7 +593,10 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     double* wsp = plan->d_ws;
     const long long* wso = plan->d_ws_off;
     void* kargs[] = {(void*)&k, (void*)&wsp, (void*)&wso};
-    HIP_TRY(h, hipLaunchKernel(ki.fn, dim3((unsigned)cnt), dim3((unsigned)ki.threads), kargs, ki.smem, pick_stream(false)));
+    slow_tier = true;
+    hipStream_t sl = pick_stream(false);
+    slow_tier = false;
+    HIP_TRY(h, hipLaunchKernel(ki.fn, dim3((unsigned)cnt), dim3((unsigned)ki.threads), kargs, ki.smem, sl));
   }
   if (plan->bin_count[BIN_TOO_LARGE] > 0) {
     const int64_t cnt = plan->bin_count[BIN_TOO_LARGE];
@@ -605,7 +617,9 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     const int bin = nf == 1 ? BIN_SMALL1 : BIN_SMALL2;
     const int64_t cnt = plan->bin_count[bin];
     if (cnt == 0) continue;
+    slow_tier = nf == 2;
     hipStream_t st = pick_stream(nf == 1);
+    slow_tier = false;
     if (gate && nf != 1) (void)hipStreamWaitEvent(st, h->ev_gate, 0);
     int* counter = h->d_counter + nf;
     k.order = ord + plan->bin_begin[bin];

@@ -70,8 +70,15 @@ enum { CTR_CONS_NONE = 0, CTR_CONS_DIMER = 1, CTR_CONS_TRIMER = 2, CTR_CONS_TETR
  * CTR_FLAG_THROUGHPUT: the caller keeps several batches in flight on one device (one handle
  * each); favour machine time per cluster over the latency of one batch -- pairs that are not
  * likely to be slow fits share a wavefront four at a time, larger 2D clusters run on the
- * fewest wavefronts. */
-enum { CTR_FLAG_THROUGHPUT = 1 };
+ * fewest wavefronts.
+ * CTR_FLAG_ISOLATE_TAIL: for batches that hold a fit far slower than the rest (e.g. two start
+ * positions on one real feature: hundreds of iterations) while several batches are in flight:
+ * only the kernel that takes the likely slow fits runs beside the handle's main stream, all other
+ * size classes follow each other on the main stream.  A handle then keeps two hardware queues
+ * busy instead of four, and with eight handles no long kernel shares a queue with the start of
+ * another handle's next batch (a queue is served in order).  Costs 10-15 % on batches without
+ * such a fit, gains 20-30 % on batches with one; a caller can time both. */
+enum { CTR_FLAG_THROUGHPUT = 1, CTR_FLAG_ISOLATE_TAIL = 2 };
 
 /* per-cluster status */
 enum {

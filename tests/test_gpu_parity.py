@@ -123,6 +123,16 @@ def test_cfg2_throughput_flag_changes_scheduling_not_results(engine, oracle, cfg
     assert_allclose(b1.params_out, b0.params_out, rtol=0, atol=1e-9)
     assert_allclose(b1.cost, b0.cost, rtol=1e-12, equal_nan=True)
     assert_batches_close(b1, ref, slice(2, 4), atol=1e-6)
+    # CTR_FLAG_ISOLATE_TAIL moves kernels between streams, nothing else: bit for bit the same
+    for flags in (_abi.FLAG_ISOLATE_TAIL, _abi.FLAG_ISOLATE_TAIL | _abi.FLAG_THROUGHPUT):
+        b2 = clone_batch(prep.batch)
+        prob2 = copy.copy(prep.problem)
+        prob2.flags |= flags
+        engine.refine_batch(prob2, b2)
+        same = b1 if flags & _abi.FLAG_THROUGHPUT else b0
+        assert_equal(b2.status, same.status)
+        assert_equal(b2.params_out, same.params_out)
+        assert_equal(b2.cost, same.cost)
 
 
 def test_cfg2_cluster_order_invariance(engine, cfg2_full):
