@@ -213,6 +213,7 @@ def main():
     # and without a process group (from 24 queues on, every small kernel of the chain -- fill,
     # frame maximum, ordering -- takes ~0.1 ms instead of ~0.02 ms on this runtime).
     os.environ.setdefault('GPU_MAX_HW_QUEUES', str(min(20, max(4, 2 * max(1, args.in_flight)))))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC (the inbox, RCCL)
     import torch
     import torch.distributed as dist
     import clustertracking_amd as cta
@@ -252,7 +253,9 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world,
                                     device_id=torch.device('cuda', local_rank))
         else:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
+            import datetime
+            dist.init_process_group('gloo', rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=600))   # (a rank that died must not hold the others for half an hour)
 
     # ---- this rank's shard: frames [rank*F, (rank+1)*F) of the video --------------
     shard = rank if args.shard is None else args.shard
