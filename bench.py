@@ -64,9 +64,10 @@ def parse():
                          "'rccl' when the inbox cannot be mapped); 'rccl' = an asynchronous gather per step, "
                          "issued from the host as steps finish (ctr_query_done)")
     ap.add_argument('--layout', default='auto', choices=['auto', 'default', 'tail'],
-                    help="stream layout of the engines: 'tail' = CTR_FLAG_ISOLATE_TAIL (only the kernel of the "
-                         "likely slow fits beside the main stream); 'auto' (default) times a few steps of both "
-                         "before the warm-up and keeps 'tail' where it is at least 7 %% faster")
+                    help="stream layout of the engines: 'tail' = CTR_FLAG_ISOLATE_TAIL (the kernel of the likely "
+                         "slow fits on a stream whose hardware queue no main stream shares); 'auto' (default) "
+                         "times a few steps of both before the warm-up and keeps 'tail' where it is at least "
+                         "7 %% faster")
     ap.add_argument('--single-device', action='store_true',
                     help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()

@@ -526,18 +526,21 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
   HIP_TRY(h, hipEventRecord(h->ev_fork, s));
   bool used[NSIDE] = {};
   int next_side = 0;
-  // CTR_FLAG_ISOLATE_TAIL: only the tier of the likely slow fits (the 64-lane pairs kernel, the
-  // large-cluster kernel) leaves the main stream
+  // Which side stream a kernel takes.  Default: round robin in launch order.  With
+  // CTR_FLAG_ISOLATE_TAIL the tier of the likely slow fits (the 64-lane pairs kernel, the
+  // large-cluster kernel) has side stream 1 to itself and the others alternate between 0 and 2:
+  // with 4 streams per handle on 2 hardware queues per handle, stream k of a handle shares its
+  // queue with stream 3 - k of another handle (0 = main), so a long kernel on side 1 holds up
+  // that handle's side-0 kernels -- not its main stream, on which its next batch begins (a slow
+  // kernel in front of another handle's main stream delays that handle's whole next batch, slow
+  // kernel included: the delays chain).
   const bool isolate = (p.flags & CTR_FLAG_ISOLATE_TAIL) != 0;
   bool slow_tier = false;
   auto pick_stream = [&](bool main_stream) -> hipStream_t {
     if (main_stream) return s;
-    if (isolate) {
-      if (!slow_tier) return s;
-      if (!used[0]) { used[0] = true; (void)hipStreamWaitEvent(h->side[0], h->ev_fork, 0); }
-      return h->side[0];
-    }
-    const int j = next_side++ % NSIDE;
+    int j;
+    if (isolate) j = slow_tier ? 1 : (next_side++ % 2 == 0 ? 0 : 2);
+    else j = next_side++ % NSIDE;
     if (!used[j]) { used[j] = true; (void)hipStreamWaitEvent(h->side[j], h->ev_fork, 0); }
     return h->side[j];
   };

@@ -73,11 +73,11 @@ enum { CTR_CONS_NONE = 0, CTR_CONS_DIMER = 1, CTR_CONS_TRIMER = 2, CTR_CONS_TETR
  * fewest wavefronts.
  * CTR_FLAG_ISOLATE_TAIL: for batches that hold a fit far slower than the rest (e.g. two start
  * positions on one real feature: hundreds of iterations) while several batches are in flight:
- * only the kernel that takes the likely slow fits runs beside the handle's main stream, all other
- * size classes follow each other on the main stream.  A handle then keeps two hardware queues
- * busy instead of four, and with eight handles no long kernel shares a queue with the start of
- * another handle's next batch (a queue is served in order).  Costs 10-15 % on batches without
- * such a fit, gains 20-30 % on batches with one; a caller can time both. */
+ * the kernel that takes the likely slow fits gets a stream to itself whose hardware queue it
+ * does not share with the main stream of another handle (a queue is served in order: a long
+ * kernel in front of a main stream delays that handle's whole next batch).  Costs 10-15 % on
+ * batches without such a fit, gains 30 % on batches with one; a caller can time
+ * both.  Assumes 2 hardware queues per handle (GPU_MAX_HW_QUEUES = 2 x handles in flight). */
 enum { CTR_FLAG_THROUGHPUT = 1, CTR_FLAG_ISOLATE_TAIL = 2 };
 
 /* per-cluster status */
