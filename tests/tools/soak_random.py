@@ -1,6 +1,6 @@
 """Soak test: many random configurations, engine vs C oracle (tests/test_gpu_parity.py's
 generator with more seeds).   python tests/tools/soak_random.py [n_seeds] [first_seed]
-Environment: SOAK_CONSTRAINED_ONLY, SOAK_THROUGHPUT (scheduling flag), SOAK_LOWPASS (a random
+Environment: SOAK_CONSTRAINED_ONLY, SOAK_THROUGHPUT / SOAK_ISOLATE (scheduling flags), SOAK_LOWPASS (a random
 noise_size / threshold per configuration), SOAK_STD (also compare params_std)."""
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')
@@ -37,6 +37,8 @@ for seed in range(first, first + n_seeds):
     prep = cta.prepare_batch(f0, im, diameter, compute_error=want_std, **kw)
     if os.environ.get('SOAK_THROUGHPUT'):
         prep.problem.flags |= _abi.FLAG_THROUGHPUT   # scheduling flag: same results expected
+    if os.environ.get('SOAK_ISOLATE'):
+        prep.problem.flags |= _abi.FLAG_ISOLATE_TAIL
     b = prep.batch
     ref = _abi.HostBatch(b.frames, b.frame_index, b.feat_offset, b.params, b.low, b.high, want_std=want_std)
     eng.refine_batch(prep.problem, b)
