@@ -978,7 +978,9 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         int cg_it = 0;
         for (int ci = 0; ci < cg_max && !cg_fail && rz[0] > cg_tol2 * rz0 && rz[0] > 0.; ++ci) {
           ++cg_it;
+          const unsigned long long tm0 = __builtin_amdgcn_s_memrealtime();
           const double pAp = matvec(ps, Aps, tl, ol, mu, nwt, fre);
+          if (tid == 0) atomicAdd(&g_large_dbg[3], __builtin_amdgcn_s_memrealtime() - tm0);
           if (!(pAp > 0.) || !isfinite(pAp)) { cg_fail = true; break; }   // not positive definite
           const double alpha = rz[0] / pAp;
           for (int i = tid; i < n; i += LT)

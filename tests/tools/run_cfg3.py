@@ -25,7 +25,7 @@ dbg = (ctypes.c_ulonglong * 8)()
 if hasattr(eng._lib, 'ctr_debug_large_counters') and eng._lib.ctr_debug_large_counters(dbg, 1) == 0:
     print('large path (both runs): solves %d, CG iterations %d (%.1f per solve), pixel passes %d' % (
         dbg[0], dbg[1], dbg[1] / max(dbg[0], 1), dbg[2]))
-    print('  time in pixel passes %.3f s, in solves %.3f s (summed over clusters)' % (dbg[4] * 1e-8, dbg[5] * 1e-8))
+    print('  time in pixel passes %.3f s, in solves %.3f s of which matrix-vector products %.3f s (summed over clusters)' % (dbg[4] * 1e-8, dbg[5] * 1e-8, dbg[3] * 1e-8))
     print('  wave 0: feature tiles %.3f s, pair blocks %.3f s' % (dbg[6] * 1e-8, dbg[7] * 1e-8))
 print('status counts', np.bincount(b.status), 'rounds', b.n_rounds[:8], 'iters', b.n_iter[:8])
 out = np.empty_like(b.params_out); out[prep.order] = b.params_out
