@@ -58,7 +58,7 @@ constexpr int LARGE_MAXNB = 48;   // neighbours (features with overlapping mask 
 
 struct LargeWs {
   long long nvp, nvp_i;   // variables / features rounded up to a multiple of 8
-  long long o_vec, o_cur, o_mco, o_fpar, o_pre, o_uq, o_tile, o_off, o_int, total;
+  long long o_vec, o_cur, o_mco, o_fpar, o_pre, o_uq, o_tile, o_off, o_offc, o_int, total;
 };
 
 // n features, npf per-feature and ns shared variables
@@ -76,6 +76,7 @@ __host__ __device__ inline LargeWs large_ws(int n, int npf, int ns) {
   W.o_uq = o;   o += W.nvp_i * 16;               // second-order entries + raw sums
   W.o_tile = o; o += 2 * nn * 256;               // accepted / trial 16 x 16 tiles
   W.o_off = o;  o += 2 * nn * LARGE_MAXNB * 64;  // accepted / trial neighbour blocks
+  W.o_offc = o; o += nn * LARGE_MAXNB * npf * npf;  // accepted blocks, packed (the CG's copy)
   W.o_int = o;  o += (W.nvp_i + 2 * nn * LARGE_MAXNB + 1) / 2 + 8;   // nbcnt, nbidx, rev (int32)
   W.total = (o + 31) & ~31LL;
   return W;

@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
   double* tileB = tileA + (size_t)n * 256;       // trial point
   double* offA = ws + W.o_off;
   double* offB = offA + (size_t)n * LARGE_MAXNB * 64;
+  double* offC = ws + W.o_offc;                  // accepted blocks packed NPF x NPF (matvec)
   int* nbcnt = (int*)(ws + W.o_int);
   int* nbidx = nbcnt + W.nvp_i;
   int* rev = nbidx + (size_t)n * LARGE_MAXNB;
@@ -620,10 +621,14 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       }
       const int cnt = nbcnt[i];
       const int* nb = nbidx + (size_t)i * LARGE_MAXNB;
-      const double* o = off + (size_t)i * LARGE_MAXNB * 64 + a * 8;
+      // (the packed copy of the accepted blocks: a block is NPF x NPF contiguous doubles, one or
+      //  two cache lines, instead of NPF half-lines spread over 512 bytes -- the products of a
+      //  solve read them ~200 times, through one CU's L2 port)
+      (void)off;
+      const double* o = offC + (size_t)i * LARGE_MAXNB * NPF * NPF + a * NPF;
       for (int s2 = 0; s2 < cnt; ++s2) {
         const double* xj = x + NS + nb[s2] * NPF;
-        const double* ob = o + s2 * 64;
+        const double* ob = o + s2 * NPF * NPF;
 #pragma unroll
         for (int b = 0; b < MAXPF; ++b)
           if (b < NPF) s += ob[b] * xj[b];
@@ -817,6 +822,21 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       ++iters;
       const double* tl = tiles_swapped ? tileB : tileA;
       const double* ol = tiles_swapped ? offB : offA;
+      // pack the accepted neighbour blocks for the matrix-vector products of this iteration
+      {
+        const int per = NPF * NPF;
+        for (int i = wave; i < n; i += LW) {
+          const int cnt = nbcnt[i];
+          const double* src = ol + (size_t)i * LARGE_MAXNB * 64;
+          double* dst = offC + (size_t)i * LARGE_MAXNB * per;
+          for (int e = lane; e < cnt * per; e += WAVE) {
+            const int s2 = e / per, r = e - s2 * per;
+            const int a = r / NPF, b = r - a * NPF;
+            dst[e] = src[s2 * 64 + a * 8 + b];
+          }
+        }
+        __syncthreads();
+      }
       // active set: fixed if at a bound and the gradient pushes outward
       double nfv[1] = {0.};
       for (int i = tid; i < nv; i += LT) {
