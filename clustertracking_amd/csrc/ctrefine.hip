@@ -715,6 +715,18 @@ int ctr_ipc_open(ctr_handle* h, const unsigned char* handle, void** dev_ptr) {
   void* p = nullptr;
   const hipError_t e = hipIpcOpenMemHandle(&p, ih, hipIpcMemLazyEnablePeerAccess);
   if (e != hipSuccess) return fail(h, CTR_ERR_DEVICE, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+  // a kernel of this device will store there: refuse a block on a device it has no peer access to
+  // (a store that faults can take the GPUs of the node down; the caller falls back to RCCL)
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.device != h->device) {
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, h->device, attr.device) != hipSuccess || !can) {
+      (void)hipIpcCloseMemHandle(p);
+      return fail(h, CTR_ERR_DEVICE, "no peer access from this device to the device that owns the block");
+    }
+  } else {
+    (void)hipGetLastError();
+  }
   *dev_ptr = p;
   return CTR_OK;
 }
