@@ -42,7 +42,7 @@ def parse():
                          "the N > 1 code path on a one-GPU box)")
     ap.add_argument('--features', type=int, default=None,
                     help="features per frame/stack (default: the workload's own)")
-    ap.add_argument('--in-flight', type=int, default=8,
+    ap.add_argument('--in-flight', type=int, default=10,
                     help="batches in flight per GPU: step k starts while the slowest clusters of "
                          "steps k-1.. are still being fitted (one engine handle and one set of "
                          "output buffers per batch in flight)")
@@ -208,9 +208,10 @@ def main():
     # ROCm's default of 4 per process, or kernels of different streams queue up behind each
     # other.  Read by the HIP runtime when it initialises, hence set before torch is imported.
     # An engine handle has 1 + 3 streams and HIP deals streams to the queues round robin: with
-    # 2 queues per batch in flight (16 for the default 8) every queue carries two streams of the
-    # same role, four handles apart.  The rate depends on that pattern -- 12 / 16 / 17 / 19 / 20 /
-    # 24 / 28 queues: 35 / 48 / 45 / 41 / 47 / 38 / 36 M fits/s -- so the SAME count is used with
+    # 2 queues per batch in flight (20 for the default 10) every queue carries two streams.  The
+    # rate depends on that pattern -- eight batches in flight on 12 / 16 / 17 / 19 / 20 / 24 / 28
+    # queues: 35 / 48 / 45 / 41 / 47 / 38 / 36 M fits/s; ten on 20 queues 49 M, and the shards with
+    # one very slow fit 45 instead of 41 M -- so the SAME count is used with
     # and without a process group (from 24 queues on, every small kernel of the chain -- fill,
     # frame maximum, ordering -- takes ~0.1 ms instead of ~0.02 ms on this runtime).
     os.environ.setdefault('GPU_MAX_HW_QUEUES', str(min(20, max(4, 2 * max(1, args.in_flight)))))

@@ -2,7 +2,7 @@
 (CTR_FLAG_THROUGHPUT), i.e. with the tails of the slow clusters hidden by the overlap.  The sum
 over the classes is about what a step of the whole workload costs in bench.py."""
 import os, sys, copy, time
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '20')
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
 import clustertracking_amd as cta

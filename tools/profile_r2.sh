@@ -4,7 +4,7 @@
 # under rocprofv3 the HIP runtime is initialised before bench.py can set the variable itself,
 # so it is exported HERE, for every run alike.  `python bench.py` comes directly after `--`.
 set -e
-export GPU_MAX_HW_QUEUES=16
+export GPU_MAX_HW_QUEUES=20
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02
 mkdir -p $O
