@@ -435,7 +435,8 @@ def main():
     # served better with CTR_FLAG_ISOLATE_TAIL (include/ctrefine.h); which it is shows in a few
     # steps of each.  Results do not depend on the flag.
     layout = 'default'
-    if nfl > 1 and args.layout != 'default':
+    has_large = prep.batch.n_clusters > 0 and int(np.diff(prep.batch.feat_offset).max()) > 64   # (their plans own GBs of workspace)
+    if nfl > 1 and args.layout != 'default' and not has_large:
         import copy
         prob_tail = copy.copy(prep.problem)
         prob_tail.flags |= _abi.FLAG_ISOLATE_TAIL
