@@ -626,12 +626,40 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       //  solve read them ~200 times, through one CU's L2 port)
       (void)off;
       const double* o = offC + (size_t)i * LARGE_MAXNB * NPF * NPF + a * NPF;
-      for (int s2 = 0; s2 < cnt; ++s2) {
-        const double* xj = x + NS + nb[s2] * NPF;
-        const double* ob = o + s2 * NPF * NPF;
+      if (NPF == 4) {
+        // four neighbours at a time, the 20 loads of a group in flight together: one block at
+        // a time the product is bound by one memory round trip per neighbour (8 wavefronts x
+        // 32 bytes per lane in flight: 27 GB/s).  Same sums in the same order.
+        int s2 = 0;
+        for (; s2 + 4 <= cnt; s2 += 4) {
+          const int j0 = nb[s2], j1 = nb[s2 + 1], j2 = nb[s2 + 2], j3 = nb[s2 + 3];
+          const double* ob = o + s2 * 16;
+          const double a00 = ob[0], a01 = ob[1], a02 = ob[2], a03 = ob[3];
+          const double a10 = ob[16], a11 = ob[17], a12 = ob[18], a13 = ob[19];
+          const double a20 = ob[32], a21 = ob[33], a22 = ob[34], a23 = ob[35];
+          const double a30 = ob[48], a31 = ob[49], a32 = ob[50], a33 = ob[51];
+          const double* x0 = x + NS + j0 * 4;
+          const double* x1 = x + NS + j1 * 4;
+          const double* x2 = x + NS + j2 * 4;
+          const double* x3 = x + NS + j3 * 4;
+          s += a00 * x0[0]; s += a01 * x0[1]; s += a02 * x0[2]; s += a03 * x0[3];
+          s += a10 * x1[0]; s += a11 * x1[1]; s += a12 * x1[2]; s += a13 * x1[3];
+          s += a20 * x2[0]; s += a21 * x2[1]; s += a22 * x2[2]; s += a23 * x2[3];
+          s += a30 * x3[0]; s += a31 * x3[1]; s += a32 * x3[2]; s += a33 * x3[3];
+        }
+        for (; s2 < cnt; ++s2) {
+          const double* xj = x + NS + nb[s2] * 4;
+          const double* ob = o + s2 * 16;
+          s += ob[0] * xj[0]; s += ob[1] * xj[1]; s += ob[2] * xj[2]; s += ob[3] * xj[3];
+        }
+      } else {
+        for (int s2 = 0; s2 < cnt; ++s2) {
+          const double* xj = x + NS + nb[s2] * NPF;
+          const double* ob = o + s2 * NPF * NPF;
 #pragma unroll
-        for (int b = 0; b < MAXPF; ++b)
-          if (b < NPF) s += ob[b] * xj[b];
+          for (int b = 0; b < MAXPF; ++b)
+            if (b < NPF) s += ob[b] * xj[b];
+        }
       }
       s *= mk ? mk[b0 + a] : 1.;
       y[b0 + a] = s;
