@@ -147,7 +147,7 @@ __device__ __forceinline__ void make_layout_b(const ctr_problem& p, int n, Layou
 
 constexpr int QT = 9;  // second-order entries kept per feature: ND (signal, pos_a) + ND(ND+1)/2 (pos_a, pos_b)
 
-template <int NT, int W>
+template <int NT, int W, bool CONS = false>
 struct SmemB {
   static constexpr int NVP = 16 * NT;
   static constexpr int RS = NVP + 1;
@@ -180,7 +180,12 @@ struct SmemB {
   static constexpr int o_uc = o_ctl + 8;
   static constexpr int o_vinfo = o_uc + NFQ * QT;       // ints: 8 * feature + kind + 1 of every variable
   static constexpr int o_cpair = o_vinfo + NVP / 2;     // ints: pair behind constraint r (current, trial)
-  static constexpr int total = o_cpair + MAXC;
+  // constrained fits (cons_qp): 1/diag of the factor, gradient of the model, and the
+  // second-order part in all variables as a packed triangle (non-default modes)
+  static constexpr int o_qd = o_cpair + MAXC;
+  static constexpr int o_gq = o_qd + (CONS ? NVP : 0);
+  static constexpr int o_Qp = o_gq + (CONS ? NVP : 0);
+  static constexpr int total = o_Qp + (CONS ? NVP * (NVP + 1) / 2 : 0);
   static constexpr size_t bytes = (size_t)total * sizeof(double);
   static_assert(W == 1 || NTILE * 256 + 6 * WAVE <= ROWS, "partial accumulators must fit a row tile");
 };
@@ -253,7 +258,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
 #ifdef CTR_STAMPS
   unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
 #endif
-  using SM = SmemB<NT, W>;
+  using SM = SmemB<NT, W, CONS>;
   constexpr int NP = 2 + ND + (ISO ? 1 : ND);
   constexpr int NSZ = ISO ? 1 : ND;
   constexpr int LDC = SM::NVC;
@@ -312,6 +317,13 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
   bool size_is_var = false;
 #pragma unroll
   for (int kk = 2 + ND; kk < NP; ++kk) size_is_var = size_is_var || L.slot[kk] >= 0;
+  // constrained fits with other than the default modes: the second-order part in ALL variables
+  // (second_order_pass after every accepted step) instead of the (signal, position) part that
+  // the pixel pass sums (same rule: oracle solve(), fullq)
+  const bool fullq = CONS && m != 0 && (!newton_on || size_is_var);
+  const bool cheapq = newton_on && !fullq;
+  newton_on = newton_on || fullq;
+  double* Qp = smem + SM::o_Qp;
   auto fill_fpar = [&](const double* vv, bool sizes) {
     bool bad_size = false;
     for (int i = lane; i < n; i += WAVE) {
@@ -465,7 +477,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
   // box; a variable on a bound that the correction would push outward is left out.  Wave 0,
   // one variable per lane (constrained clusters have at most 29 variables).  On success cvo /
   // Cjo / cpo describe the constraints at the returned point.
-  auto retract = [&](double* x, double* cvo, double* Cjo, int* cpo) -> bool {
+  auto retract = [&](double* x, double* cvo, double* Cjo, int* cpo, unsigned long long heldmask) -> bool {
     double* ry = cv + 18;   // (6 free doubles of the small block)
     const bool ranked = k.prob.constraint_kind == CTR_CONS_TETRAMER && ND == 2;
     int pairs[MAXC];
@@ -489,7 +501,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         if (iter == 30) break;
         const bool isvar = lane < nv;
         const double xi = isvar ? x[lane] : 0., li = isvar ? lo[lane] : 0., ui = isvar ? hi[lane] : 0.;
-        bool pinned = !isvar || !(li < ui);
+        bool pinned = !isvar || !(li < ui) || ((heldmask >> lane) & 1ull) != 0ull;
         double ti = 0.;
         for (int pass = 0; pass < 2; ++pass) {
           const unsigned long long fm = __ballot(!pinned);
@@ -534,6 +546,132 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
       wsync();
     }
     return false;
+  };
+
+  // Sum_p res_p d2res_p/dv dv in ALL variables at v (oracle full_second_order), added to the
+  // packed lower triangle dest[tri(nv)]; wave 0, fpar filled for v.  wsum: 28 doubles of scratch.
+  // Used by compute_error (refine.py:400-406) and, for constrained fits with other than the
+  // default modes, as the second-order part of the solver's model.
+  auto second_order_pass = [&](double* dest, double* wsum) {
+        // per feature the second derivatives of m = s g, g = exp(E), in parameter space
+        // (signal, centres, sizes): m_s,t = g E_t, m_t,u = s g (E_t E_u + E_tu); entry (t <= u) of
+        // the PW x PW block at PWI(t, u); lane e = PW t + u adds it to the packed H at the
+        // variables the two parameters map to
+        constexpr int PW = 1 + ND + NSZ, NW = PW * (PW + 1) / 2, NG = (NW + 3) / 4;
+        int origin[ND], wshape[ND];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) { origin[a] = ctl[1 + a]; wshape[a] = ctl[4 + a]; }
+        const int w1 = wshape[ND - 2], w2 = wshape[ND - 1];
+        const int npix = (ND == 3 ? wshape[0] : 1) * w1 * w2;
+        const double bg = par(v, 0, 0);
+        const int et = lane / PW, eu = lane - et * PW;
+        const int widx = et <= eu ? et * PW - (et * (et - 1)) / 2 + (eu - et)
+                                  : eu * PW - (eu * (eu - 1)) / 2 + (et - eu);
+        for (int base = 0; base < npix; base += WAVE) {
+          const int q = base + lane;
+          const bool valid = q < npix;
+          int idx[ND];
+          size_t off;
+          {
+            const int t = q / w2, x = q - t * w2;
+            if (ND == 3) {
+              const int z = t / w1, y = t - z * w1;
+              idx[0] = z; idx[1] = y; idx[ND - 1] = x;
+              off = ((size_t)(z + origin[0]) * fshape[1] + (y + origin[1])) * fshape[ND - 1] + (x + origin[ND - 1]);
+            } else {
+              idx[0] = t; idx[ND - 1] = x;
+              off = (size_t)(t + origin[0]) * fshape[ND - 1] + (x + origin[ND - 1]);
+            }
+          }
+          unsigned long long mine = 0ull;
+          double model = 0.;
+          for (int i = 0; i < n; ++i) {
+            double rel[ND];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) rel[a] = mco[i * 3 + a] - (double)origin[a];
+            if (valid && in_mask<ND>(idx, rel, inv_r2, radius)) {
+              const double* f = fpar + i * FP;
+              double r2 = 0.;
+#pragma unroll
+              for (int a = 0; a < ND; ++a) {
+                const double d = (double)(idx[a] + origin[a]) - f[1 + a];
+                r2 += d * d * f[4 + a];
+              }
+              model += f[0] * exp(-0.5 * ND * r2);
+              mine |= 1ull << i;
+            }
+          }
+          double resg = 0.;
+          if (mine != 0ull) {
+            double pixv;
+            if constexpr (LP) pixv = lowpass_pixel<ND>(frame, k.frame_dtype, fshape, origin, wshape, idx, k.lp_w, k.lp_half, k.prob.threshold);
+            else pixv = load_pixel(frame, k.frame_dtype, off);
+            const double res = pixv - bg - model;
+            resg = res == res ? res : 0.;  // nansum
+          }
+          for (int i = 0; i < n; ++i) {
+            const bool in = ((mine >> i) & 1ull) != 0ull;
+            if (__ballot(in) == 0ull) continue;
+            const double* f = fpar + i * FP;
+            double E1[PW], dd[ND], i2z[ND], q2 = 0., r2 = 0.;
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              dd[a] = (double)(idx[a] + origin[a]) - f[1 + a];
+              i2z[a] = -0.5 * f[10 + a];   // 1 / size^3
+              q2 += dd[a] * dd[a];
+              r2 += dd[a] * dd[a] * f[4 + a];
+            }
+            const double G = in ? exp(-0.5 * ND * r2) : 0.;
+            const double sg = f[0] * G, mr = -resg;   // d2res = -d2m
+            E1[0] = 0.;
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              E1[1 + a] = (double)ND * dd[a] * f[4 + a];
+              if (!ISO) E1[(1 + ND + a) % PW] = (double)ND * dd[a] * dd[a] * i2z[a];
+            }
+            if (ISO) E1[1 + ND] = (double)ND * q2 * i2z[0];
+            auto hval = [&](int t, int u) -> double {   // t <= u, compile-time after unrolling
+              if (u == 0) return 0.;
+              if (t == 0) return G * E1[u];
+              double h = sg * (E1[t] * E1[u]), e2 = 0.;
+              const int a = t - 1;
+              if (u <= ND) {
+                if (t == u) e2 = -(double)ND * f[4 + a];
+              } else if (t <= ND) {
+                if (ISO) e2 = -2. * ND * dd[a] * i2z[0];
+                else if (u - 1 - ND == a) e2 = -2. * ND * dd[a] * i2z[a];
+              } else {
+                if (ISO) e2 = -3. * ND * q2 * f[4] * f[4];
+                else if (t == u) {
+                  const int b = t - 1 - ND;
+                  e2 = -3. * ND * dd[b] * dd[b] * f[4 + b] * f[4 + b];
+                }
+              }
+              return h + sg * e2;
+            };
+            double hv[4 * NG];
+            {
+              int e = 0;
+#pragma unroll
+              for (int t = 0; t < PW; ++t)
+#pragma unroll
+                for (int u = t; u < PW; ++u) hv[e++] = mr * hval(t, u);
+#pragma unroll
+              for (; e < 4 * NG; ++e) hv[e] = 0.;
+            }
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) {
+              const double t4 = wave_sum4(hv[4 * gq], hv[4 * gq + 1], hv[4 * gq + 2], hv[4 * gq + 3], lane);
+              if ((lane & 15) == 0) wsum[4 * gq + (lane >> 4)] = t4;
+            }
+            wsync();
+            if (lane < PW * PW) {
+              const int ct = L.vidx(1 + et, i), cu = L.vidx(1 + eu, i);
+              if (ct >= 0 && cu >= 0 && ct >= cu) dest[tri(ct) + cu] += wsum[widx];
+            }
+            wsync();
+          }
+        }
   };
 
   // ---- set-up (all threads) ---------------------------------------------------------
@@ -620,7 +758,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
     }
     wsync();
     // the start vector need not satisfy the constraints: restore feasibility first
-    retr_fail = m > 0 && !retract(vt, cvt, Cjt, cpair + MAXC);
+    retr_fail = m > 0 && !retract(vt, cvt, Cjt, cpair + MAXC, 0ull);
     fill_fpar(vt, size_is_var || round == 0);
     it = 0;
     return BP_EVAL_INIT;
@@ -793,7 +931,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         if (any && !good) {
           for (int j = 1 + L.nshared; j <= nv; ++j) row[j] = 0.;
         }
-        if (newton_on && cand != 0ull) {
+        if (cheapq && cand != 0ull) {
           // second pass over the candidates, now that the residual is complete: the lanes'
           // res * J_pos_a * dE/dpos_b are summed over the tile (four sums per exchange
           // sequence) and land in the accumulators of lane i = the feature
@@ -969,7 +1107,16 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         }
         S = St;
         wsync();
-        if (newton_on && lane < n) {
+        if constexpr (CONS) {
+          if (fullq) {
+            for (int e = lane; e < tri(nv); e += WAVE) Qp[e] = 0.;
+            fill_fpar(v, true);
+            wsync();
+            second_order_pass(Qp, Y);
+            wsync();
+          }
+        }
+        if (cheapq && lane < n) {
           // second-order entries of feature `lane` at the new point: U from the pixel pass,
           // the rest from the gradient (oracle eval_cluster): d2res/ds dpos_a = g_pos_a / s,
           // d2res/dpos_a dpos_b = U_ab + delta_ab (-ND/size_a^2) s g_s
@@ -1009,27 +1156,45 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         double mult0[MAXC];
 #pragma unroll
         for (int r = 0; r < MAXC; ++r) mult0[r] = 0.;
+        unsigned long long freemask = 0ull;   // constrained fits: the free variables
         if (m) {
+          // two passes (oracle solve()): the multipliers over all variables the box does not fix
+          // give a first active set; the multipliers over the variables THAT leaves free give
+          // the active set used
           double* ry = cv + 18;
-          if (lane < m * m) {
-            const int r = lane / (m > 0 ? m : 1), s2 = lane % (m > 0 ? m : 1);
-            double t = 0.;
-            for (int i = 0; i < nv; ++i)
-              if (lo[i] < hi[i]) t += Cj[r * LDC + i] * Cj[s2 * LDC + i];
-            Sc[r * MAXC + s2] = t;
-          }
-          if (lane < m) {
-            double t = 0.;
-            for (int i = 0; i < nv; ++i)
-              if (lo[i] < hi[i]) t -= Cj[lane * LDC + i] * Mp[tri(i + 1)];
-            ry[lane] = t;
-          }
-          wsync();
-          small_spd_solve(Sc, ry);
-          const bool okl = flag[0] != 0.;
+          for (int pass = 0; pass < 2; ++pass) {
+            const unsigned long long inset = pass == 0
+                ? __ballot(lane < nv && lo[lane < nv ? lane : 0] < hi[lane < nv ? lane : 0]) : freemask;
+            if (lane < m * m) {
+              const int r = lane / (m > 0 ? m : 1), s2 = lane % (m > 0 ? m : 1);
+              double t = 0.;
+              for (int i = 0; i < nv; ++i)
+                if ((inset >> i) & 1ull) t += Cj[r * LDC + i] * Cj[s2 * LDC + i];
+              Sc[r * MAXC + s2] = t;
+            }
+            if (lane < m) {
+              double t = 0.;
+              for (int i = 0; i < nv; ++i)
+                if ((inset >> i) & 1ull) t -= Cj[lane * LDC + i] * Mp[tri(i + 1)];
+              ry[lane] = t;
+            }
+            wsync();
+            small_spd_solve(Sc, ry);
+            const bool okl = flag[0] != 0.;
 #pragma unroll
-          for (int r = 0; r < MAXC; ++r) mult0[r] = (okl && r < m) ? ry[r] : 0.;
-          wsync();
+            for (int r = 0; r < MAXC; ++r)
+              if (pass == 0 || okl) mult0[r] = (okl && r < m) ? ry[r] : 0.;
+            wsync();
+            bool fre = false;
+            if (lane < nv) {
+              double gl = Mp[tri(lane + 1)];
+#pragma unroll
+              for (int r = 0; r < MAXC; ++r)
+                if (r < m) gl += Cj[r * LDC + lane] * mult0[r];
+              fre = !((lo[lane] == hi[lane]) || (v[lane] <= lo[lane] && gl > 0.) || (v[lane] >= hi[lane] && gl < 0.));
+            }
+            freemask = __ballot(fre);
+          }
         }
         // active set: fixed if at a bound and the Lagrangian gradient pushes outward
         int nf = 0;
@@ -1041,15 +1206,16 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             is_free = !((lo[lane] == hi[lane]) || (v[lane] <= lo[lane] && gl > 0.) || (v[lane] >= hi[lane] && gl < 0.));
           }
           nf = __popcll(__ballot(is_free));
+        } else if (m) {
+          nf = __popcll(freemask);
+          if ((freemask >> lane) & 1ull) fr[__popcll(freemask & ((1ull << lane) - 1ull))] = lane;
+          wsync();
         } else {
           for (int b0 = 0; b0 < nv; b0 += WAVE) {
             const int i = b0 + lane;
             bool fre = false;
             if (i < nv) {
-              double gl = Mp[tri(i + 1)];
-#pragma unroll
-              for (int r = 0; r < MAXC; ++r)
-                if (r < m) gl += Cj[r * LDC + i] * mult0[r];
+              const double gl = Mp[tri(i + 1)];
               const bool fixed = (lo[i] == hi[i]) || (v[i] <= lo[i] && gl > 0.) || (v[i] >= hi[i] && gl < 0.);
               fre = !fixed;
             }
@@ -1074,6 +1240,9 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
           double stepmax = 0.;
           // second-order part between two variables (0 unless both belong to one feature)
           auto qvar = [&](int gi, int gj) -> double {
+            if constexpr (CONS) {
+              if (fullq) return gi >= gj ? Qp[tri(gi) + gj] : Qp[tri(gj) + gi];
+            }
             const int ia = vinfo[gi], ib = vinfo[gj];
             const int ka = (ia & 7) - 1, kb = (ib & 7) - 1;
             const bool hit = ia >= 0 && ((ia ^ ib) >> 3) == 0 && ka >= 0 && kb >= 0 && ka + kb > 0;
@@ -1126,6 +1295,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
             const bool use_cc = m != 0 && attempt >= 1;             // with the constraints' curvature
             bool ok_a = true;
             bool have_dl = false;
+            unsigned long long heldmask = 0ull, lowmask = 0ull;   // constrained fits: the QP's working set
             if (reg_solve) {
              if constexpr (NT <= 2) {
               // small unconstrained system: one column per lane, in registers
@@ -1143,6 +1313,143 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
                 else ok_a = column_solve<32>(Mp, nv, mu, is_free, lane, x_own, nwt, vinfo, ic, qk);
               }
               if (ok_a && lane < nv) dl[lane] = -x_own;
+              wsync();
+              have_dl = true;
+             }
+            } else if (CONS && m != 0) {
+             if constexpr (CONS) {
+              // Constrained fit: the bound-constrained QP on the tangent space (oracle cons_qp()):
+              //   minimise g.d + 1/2 d.H.d   subject to   C d = 0,   lo - v <= d <= hi - v
+              // by a primal active-set iteration; lane i = variable i (at most 29 of them).
+              // held: -1 / +1 = kept on its lower / upper bound, 0 = free.  The sub-problems on
+              // the free variables are solved in range-space form with H_FF + rho C_F^T C_F
+              // (same minimiser on C p = 0, positive definite whenever the reduced Hessian is).
+              double* dinvq = smem + SM::o_qd;
+              double* gq = smem + SM::o_gq;
+              const bool isv = lane < nv;
+              const int li = isv ? lane : 0;
+              auto Hm = [&](int i, int j) -> double {
+                double h = Msym(Mp, i + 1, j + 1);
+                const double hs = i == j ? mu * (h > 1e-300 ? h : 1.) : 0.;
+                if (nwt) h += qvar(i, j);
+                if (use_cc) h += ccurv(i, j);
+                return h + hs;
+              };
+              int held = !isv ? 2 : (((freemask >> lane) & 1ull) ? 0 : (v[li] <= lo[li] ? -1 : 1));
+              if (isv) dl[lane] = 0.;
+              if (lane < MAXC) mult[lane] = 0.;
+              wsync();
+              int released = 0;
+              const int qp_maxit = 3 * nv + 8;
+              for (int qit = 0; qit < qp_maxit; ++qit) {
+                const unsigned long long fb = __ballot(held == 0);
+                const int nq = __popcll(fb);
+                if (nq == 0) break;
+                if (held == 0) fr[__popcll(fb & ((1ull << lane) - 1ull))] = lane;
+                if (isv) {
+                  double t = Mp[tri(lane + 1)];
+                  for (int j = 0; j < nv; ++j) t += Hm(lane, j) * dl[j];
+                  gq[lane] = t;
+                }
+                wsync();
+                const double hmax = wave_max(held == 0 ? Hm(li, li) : 0.);
+                double cm = 0.;
+                if (lane < m)
+                  for (int a = 0; a < nq; ++a) { const double c1 = Cj[lane * LDC + fr[a]]; cm += c1 * c1; }
+                const double cmax = wave_max(cm);
+                const double rho = cmax > 0. ? CTR_QP_RHO * hmax / cmax : 0.;
+                for (int e = lane; e < tri(nq); e += WAVE) {
+                  int a = (int)((sqrt(8. * e + 1.) - 1.) * 0.5);
+                  while (tri(a + 1) <= e) ++a;
+                  while (tri(a) > e) --a;
+                  const int b = e - tri(a);
+                  double t = Hm(fr[a], fr[b]);
+                  for (int r = 0; r < m; ++r) t += rho * Cj[r * LDC + fr[a]] * Cj[r * LDC + fr[b]];
+                  Hp[e] = t;
+                }
+                wsync();
+                if (!chol_factor_w(Hp, dinvq, nq, lane)) { ok_a = false; break; }
+                for (int a = lane; a < nq; a += WAVE) {
+                  w[a] = gq[fr[a]];
+                  for (int r = 0; r < m; ++r) Y[r * LDC + a] = Cj[r * LDC + fr[a]];
+                }
+                wsync();
+                chol_solve_w(Hp, dinvq, nq, w, 1, 0, lane);
+                chol_solve_w(Hp, dinvq, nq, Y, m, LDC, lane);
+                if (lane < m * m) {
+                  const int r = lane / m, s2 = lane % m;
+                  double t = 0.;
+                  for (int a = 0; a < nq; ++a) t += Cj[r * LDC + fr[a]] * Y[s2 * LDC + a];
+                  Sc[r * MAXC + s2] = t;
+                }
+                if (lane < m) {
+                  double t = 0.;
+                  for (int a = 0; a < nq; ++a) t -= Cj[lane * LDC + fr[a]] * w[a];
+                  mult[lane] = t;
+                }
+                wsync();
+                small_spd_solve(Sc, mult);
+                if (flag[0] == 0. && lane < MAXC) mult[lane] = 0.;
+                wsync();
+                // p = -H'^-1 (gq + C^T mult) of free variable fr[lane]; the ratio test along p
+                double pa = 0., rel = 0., ratio = INFINITY;
+                int vi = 0;
+                if (lane < nq) {
+                  vi = fr[lane];
+                  double t = w[lane];
+                  for (int r = 0; r < m; ++r) t += Y[r * LDC + lane] * mult[r];
+                  pa = -t;
+                  const double room = pa < 0. ? (lo[vi] - v[vi]) - dl[vi] : (hi[vi] - v[vi]) - dl[vi];
+                  rel = fabs(pa) / (fabs(v[vi]) + 1.);
+                  if (pa != 0.) ratio = room / pa;
+                }
+                const double pmax = wave_max(rel);
+                const double rmin = -wave_max(-ratio);
+                double alpha = rmin < 1. ? rmin : 1.;
+                const unsigned long long blk = __ballot(lane < nq && rmin < 1. && ratio == rmin);
+                const int blane = blk != 0ull ? __builtin_ctzll(blk) : -1;
+                if (alpha < 0.) alpha = 0.;
+                const int bvar = blane >= 0 ? __shfl(vi, blane) : -1;
+                const int bside = blane >= 0 ? (__shfl(pa, blane) < 0. ? -1 : 1) : 0;
+                wsync();
+                if (pmax > 1e-15) {
+                  if (lane < nq) dl[vi] += alpha * pa;
+                  wsync();
+                  if (bvar >= 0) {
+                    if (lane == bvar) {
+                      held = bside;
+                      dl[lane] = (bside < 0 ? lo[lane] : hi[lane]) - v[lane];
+                    }
+                    wsync();
+                    continue;
+                  }
+                  if (isv) {   // gradient of the model at the new d
+                    double t = Mp[tri(lane + 1)];
+                    for (int j = 0; j < nv; ++j) t += Hm(lane, j) * dl[j];
+                    gq[lane] = t;
+                  }
+                  wsync();
+                }
+                // a minimiser on this working set: does a held variable want to leave its bound?
+                double viol = 0.;
+                if (isv && held != 0 && lo[li] < hi[li]) {
+                  double s = gq[lane], sc = fabs(s);
+                  for (int r = 0; r < m; ++r) {
+                    const double t = Cj[r * LDC + lane] * mult[r];
+                    s += t;
+                    sc += fabs(t);
+                  }
+                  const double vv2 = held < 0 ? -s : s;   // > 0: the model falls when it moves inward
+                  viol = vv2 > 1e-10 * sc + 1e-300 ? vv2 : 0.;
+                }
+                const double wv = wave_max(viol);
+                if (!(wv > 0.) || released >= nv) break;
+                const unsigned long long wb = __ballot(viol == wv);
+                if (lane == __builtin_ctzll(wb)) held = 0;
+                ++released;
+              }
+              heldmask = __ballot(held == -1 || held == 1);
+              lowmask = __ballot(held == -1);
               wsync();
               have_dl = true;
              }
@@ -1204,13 +1511,25 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
               }
               wsync();
             }
-            // projected trial point, retracted onto the constraint manifold
+            // projected trial point, retracted onto the constraint manifold (first with the
+            // variables the QP holds on their bounds pinned, so that they stay there)
             for (int i = lane; i < nv; i += WAVE) {
               const double t = v[i] + dl[i];
-              vt[i] = t < lo[i] ? lo[i] : (t > hi[i] ? hi[i] : t);
+              double x = t < lo[i] ? lo[i] : (t > hi[i] ? hi[i] : t);
+              if (((heldmask >> i) & 1ull) && lo[i] < hi[i]) x = ((lowmask >> i) & 1ull) ? lo[i] : hi[i];
+              vt[i] = x;
+              if (m) w[i] = x;
             }
             wsync();
-            if (m && !retract(vt, cvt, Cjt, cpair + MAXC)) continue;
+            if (m) {
+              bool okr = retract(vt, cvt, Cjt, cpair + MAXC, heldmask);
+              if (!okr) {
+                for (int i = lane; i < nv; i += WAVE) vt[i] = w[i];
+                wsync();
+                okr = retract(vt, cvt, Cjt, cpair + MAXC, 0ull);
+              }
+              if (!okr) continue;
+            }
             stepmax = 0.;
             for (int i = lane; i < nv; i += WAVE) {
               const double d = vt[i] - v[i];
@@ -1231,6 +1550,8 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
 #pragma unroll
                   for (int a = 0; a < ND; ++a) t += qk[1 + a] * dl[j0 + L.slot[2 + a]];
                 }
+              } else if (nwt && fullq) {
+                for (int j = 0; j < nv; ++j) t += qvar(i, j) * dl[j];
               } else if (nwt && vinfo[i] >= 0) {
                 const int j0 = L.nshared + (vinfo[i] >> 3) * L.npf;
                 // (with constraints the model of the OBJECTIVE along the retracted step: the
@@ -1339,126 +1660,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         }
         fill_fpar(v, true);
         wsync();
-        // per feature the second derivatives of m = s g, g = exp(E), in parameter space
-        // (signal, centres, sizes): m_s,t = g E_t, m_t,u = s g (E_t E_u + E_tu); entry (t <= u) of
-        // the PW x PW block at PWI(t, u); lane e = PW t + u adds it to the packed H at the
-        // variables the two parameters map to
-        constexpr int PW = 1 + ND + NSZ, NW = PW * (PW + 1) / 2, NG = (NW + 3) / 4;
-        double* wsum = cv;   // 4 * NG <= 28 doubles of the constraint scratch (free now)
-        int origin[ND], wshape[ND];
-#pragma unroll
-        for (int a = 0; a < ND; ++a) { origin[a] = ctl[1 + a]; wshape[a] = ctl[4 + a]; }
-        const int w1 = wshape[ND - 2], w2 = wshape[ND - 1];
-        const int npix = (ND == 3 ? wshape[0] : 1) * w1 * w2;
-        const double bg = par(v, 0, 0);
-        const int et = lane / PW, eu = lane - et * PW;
-        const int widx = et <= eu ? et * PW - (et * (et - 1)) / 2 + (eu - et)
-                                  : eu * PW - (eu * (eu - 1)) / 2 + (et - eu);
-        for (int base = 0; base < npix; base += WAVE) {
-          const int q = base + lane;
-          const bool valid = q < npix;
-          int idx[ND];
-          size_t off;
-          {
-            const int t = q / w2, x = q - t * w2;
-            if (ND == 3) {
-              const int z = t / w1, y = t - z * w1;
-              idx[0] = z; idx[1] = y; idx[ND - 1] = x;
-              off = ((size_t)(z + origin[0]) * fshape[1] + (y + origin[1])) * fshape[ND - 1] + (x + origin[ND - 1]);
-            } else {
-              idx[0] = t; idx[ND - 1] = x;
-              off = (size_t)(t + origin[0]) * fshape[ND - 1] + (x + origin[ND - 1]);
-            }
-          }
-          unsigned long long mine = 0ull;
-          double model = 0.;
-          for (int i = 0; i < n; ++i) {
-            double rel[ND];
-#pragma unroll
-            for (int a = 0; a < ND; ++a) rel[a] = mco[i * 3 + a] - (double)origin[a];
-            if (valid && in_mask<ND>(idx, rel, inv_r2, radius)) {
-              const double* f = fpar + i * FP;
-              double r2 = 0.;
-#pragma unroll
-              for (int a = 0; a < ND; ++a) {
-                const double d = (double)(idx[a] + origin[a]) - f[1 + a];
-                r2 += d * d * f[4 + a];
-              }
-              model += f[0] * exp(-0.5 * ND * r2);
-              mine |= 1ull << i;
-            }
-          }
-          double resg = 0.;
-          if (mine != 0ull) {
-            double pixv;
-            if constexpr (LP) pixv = lowpass_pixel<ND>(frame, k.frame_dtype, fshape, origin, wshape, idx, k.lp_w, k.lp_half, k.prob.threshold);
-            else pixv = load_pixel(frame, k.frame_dtype, off);
-            const double res = pixv - bg - model;
-            resg = res == res ? res : 0.;  // nansum
-          }
-          for (int i = 0; i < n; ++i) {
-            const bool in = ((mine >> i) & 1ull) != 0ull;
-            if (__ballot(in) == 0ull) continue;
-            const double* f = fpar + i * FP;
-            double E1[PW], dd[ND], i2z[ND], q2 = 0., r2 = 0.;
-#pragma unroll
-            for (int a = 0; a < ND; ++a) {
-              dd[a] = (double)(idx[a] + origin[a]) - f[1 + a];
-              i2z[a] = -0.5 * f[10 + a];   // 1 / size^3
-              q2 += dd[a] * dd[a];
-              r2 += dd[a] * dd[a] * f[4 + a];
-            }
-            const double G = in ? exp(-0.5 * ND * r2) : 0.;
-            const double sg = f[0] * G, mr = -resg;   // d2res = -d2m
-            E1[0] = 0.;
-#pragma unroll
-            for (int a = 0; a < ND; ++a) {
-              E1[1 + a] = (double)ND * dd[a] * f[4 + a];
-              if (!ISO) E1[(1 + ND + a) % PW] = (double)ND * dd[a] * dd[a] * i2z[a];
-            }
-            if (ISO) E1[1 + ND] = (double)ND * q2 * i2z[0];
-            auto hval = [&](int t, int u) -> double {   // t <= u, compile-time after unrolling
-              if (u == 0) return 0.;
-              if (t == 0) return G * E1[u];
-              double h = sg * (E1[t] * E1[u]), e2 = 0.;
-              const int a = t - 1;
-              if (u <= ND) {
-                if (t == u) e2 = -(double)ND * f[4 + a];
-              } else if (t <= ND) {
-                if (ISO) e2 = -2. * ND * dd[a] * i2z[0];
-                else if (u - 1 - ND == a) e2 = -2. * ND * dd[a] * i2z[a];
-              } else {
-                if (ISO) e2 = -3. * ND * q2 * f[4] * f[4];
-                else if (t == u) {
-                  const int b = t - 1 - ND;
-                  e2 = -3. * ND * dd[b] * dd[b] * f[4 + b] * f[4 + b];
-                }
-              }
-              return h + sg * e2;
-            };
-            double hv[4 * NG];
-            {
-              int e = 0;
-#pragma unroll
-              for (int t = 0; t < PW; ++t)
-#pragma unroll
-                for (int u = t; u < PW; ++u) hv[e++] = mr * hval(t, u);
-#pragma unroll
-              for (; e < 4 * NG; ++e) hv[e] = 0.;
-            }
-#pragma unroll
-            for (int gq = 0; gq < NG; ++gq) {
-              const double t4 = wave_sum4(hv[4 * gq], hv[4 * gq + 1], hv[4 * gq + 2], hv[4 * gq + 3], lane);
-              if ((lane & 15) == 0) wsum[4 * gq + (lane >> 4)] = t4;
-            }
-            wsync();
-            if (lane < PW * PW) {
-              const int ct = L.vidx(1 + et, i), cu = L.vidx(1 + eu, i);
-              if (ct >= 0 && cu >= 0 && ct >= cu) Hp[tri(ct) + cu] += wsum[widx];
-            }
-            wsync();
-          }
-        }
+        second_order_pass(Hp, cv);   // (28 doubles of the constraint scratch, free now)
         wsync();
         pd = chol_factor_w(Hp, dl, nv, lane);
       }

@@ -9,6 +9,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int WAVE = 64;
 constexpr int MAXC = 6;       // equality constraints per cluster
+constexpr double CTR_QP_RHO = 1e3;  // weight of rho C^T C in the sub-problems of a constrained step (oracle cons_qp)
 constexpr int MAXF = 64;      // features per cluster
 constexpr int MAXNT = 8;      // 16*8 = 128 columns >= CTR_MAX_VARS + 1
 constexpr int FP = 14;        // derived per-feature constants (see fill_fpar)

@@ -19,8 +19,8 @@ template <int NT> struct WavesThroughput { static constexpr int value = NT <= 2 
 template <bool ISO, int NT, bool TP, bool CONS = false>
 KernelInfo one() {
   constexpr int W = TP ? WavesThroughput<NT>::value : WavesFor<NT>::value;
-  static_assert(SmemB<NT, W>::bytes <= LDS_CU, "LDS budget of one CU");
-  return KernelInfo{(const void*)refine_block_kernel<3, ISO, NT, W, CONS>, SmemB<NT, W>::bytes, WAVE * W};
+  static_assert(SmemB<NT, W, CONS>::bytes <= LDS_CU, "LDS budget of one CU");
+  return KernelInfo{(const void*)refine_block_kernel<3, ISO, NT, W, CONS>, SmemB<NT, W, CONS>::bytes, WAVE * W};
 }
 
 template <bool ISO, bool TP>

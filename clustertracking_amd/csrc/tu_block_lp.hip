@@ -18,8 +18,8 @@ template <int NT> struct WavesFor { static constexpr int value = NT <= 2 ? 8 : (
 template <int ND, bool ISO, int NT, bool CONS = false>
 KernelInfo one() {
   constexpr int W = WavesFor<NT>::value;
-  static_assert(SmemB<NT, W>::bytes <= LDS_CU, "LDS budget of one CU");
-  return KernelInfo{(const void*)refine_block_kernel<ND, ISO, NT, W, CONS, true>, SmemB<NT, W>::bytes, WAVE * W};
+  static_assert(SmemB<NT, W, CONS>::bytes <= LDS_CU, "LDS budget of one CU");
+  return KernelInfo{(const void*)refine_block_kernel<ND, ISO, NT, W, CONS, true>, SmemB<NT, W, CONS>::bytes, WAVE * W};
 }
 
 template <int ND, bool ISO>

@@ -535,6 +535,7 @@ void ctro_set_mu0_sizevar(double x) { mu0_sizevar = x; }
 void ctro_set_trace(int on) { trace = on; }
 
 typedef struct { double S; long P; int iters; int ok; } solve_t;
+static void full_second_order(const ctx_t* c, const double* v, double* Qf);
 
 /* Retraction onto the constraint manifold c(x) = 0 (constraints.py:59-137): minimum-norm
  * Newton steps x <- x - C^T (C C^T)^-1 c over the position variables that the box leaves
@@ -550,7 +551,7 @@ static int same_pair_set(const int* a, const int* b, int m) {
 }
 
 static int retract(const ctx_t* c, double* x, const double* lo, const double* hi,
-                   double* cv, double* Cj, int* pair_of) {
+                   double* cv, double* Cj, int* pair_of, const int* held) {
   const int nv = c->L.nv, m = c->n_cons;
   const int ranked = c->p->constraint_kind == CTR_CONS_TETRAMER && c->L.nd == 2;
   double G[MAXC * MAXC], y[MAXC];
@@ -569,7 +570,7 @@ static int retract(const ctx_t* c, double* x, const double* lo, const double* hi
       if (iter == RETRACT_MAXIT) break;
       /* pass 0: all variables the box does not fix; a variable ON a bound that this correction
        * would push outward is pinned and the correction recomputed without it (pass 1) */
-      for (int i = 0; i < nv; ++i) pinned[i] = !(lo[i] < hi[i]);
+      for (int i = 0; i < nv; ++i) pinned[i] = !(lo[i] < hi[i]) || (held && held[i]);
       for (int pass = 0; pass < 2; ++pass) {
         double tr = 0.;
         int changed = 0;
@@ -612,6 +613,134 @@ static int retract(const ctx_t* c, double* x, const double* lo, const double* hi
   return 0;
 }
 
+/* ---- the step of a constrained fit: a bound-constrained QP on the tangent space -------------
+ *   minimise  g.d + 1/2 d.H.d   subject to   C d = 0,   lo - v <= d <= hi - v
+ * (H = model Hessian + Marquardt diagonal, C = Jacobian of the equality constraints at the
+ * feasible iterate v) by a primal active-set iteration: what the reference's SLSQP solves in
+ * every major iteration (scipy slsqp_optmz.f: LSQ with the linearised constraints and the box).
+ * d = 0 is feasible; every step of the iteration lowers the model, so any iterate is a descent
+ * step of it.  held[i]: -1 / +1 = variable i is kept on its lower / upper bound (in: the start
+ * guess, out: the final working set), 0 = free.  The equality-constrained sub-problems on the free variables are solved in
+ * range-space form with H_FF + rho C_F^T C_F in place of H_FF: the same minimiser on C p = 0,
+ * and positive definite whenever the REDUCED Hessian is (the Lagrangian Hessian itself is
+ * indefinite at most constrained minima: Finsler / Debreu).
+ * Returns 0 when a sub-problem has no positive definite matrix (caller: next model). */
+#define QP_MAXIT(nv) (3 * (nv) + 8)
+static double qp_rho = 1e3;
+static int cons_use_qp = 1, lam_passes = 2, full_q_mode = 1;
+void ctro_set_full_q(int mode) { full_q_mode = mode; }
+void ctro_set_cons_qp(int on, int passes) { cons_use_qp = on; lam_passes = passes; }
+void ctro_set_qp_rho(double x) { qp_rho = x; }
+static int cons_qp(int nv, int m, const double* Hm, const double* g, const double* Cj,
+                   const double* v, const double* lo, const double* hi, int* held,
+                   double* d, double* mult) {
+  double* H = malloc(sizeof(double) * nv * nv);
+  double* gq = malloc(sizeof(double) * nv), *w = malloc(sizeof(double) * nv);
+  double* p = malloc(sizeof(double) * nv), *Y = malloc(sizeof(double) * nv * MAXC);
+  int* fr = malloc(sizeof(int) * nv);
+  double Sc[MAXC * MAXC];
+  int ok = 1, released = 0;
+  memset(d, 0, sizeof(double) * nv);
+  memset(mult, 0, sizeof(double) * MAXC);
+  for (int qit = 0; qit < QP_MAXIT(nv); ++qit) {
+    int nf = 0;
+    double hmax = 0., cmax = 0.;
+    for (int i = 0; i < nv; ++i) {
+      double t = g[i];
+      for (int j = 0; j < nv; ++j) t += Hm[i * nv + j] * d[j];
+      gq[i] = t;
+      if (!held[i]) fr[nf++] = i;
+    }
+    if (nf == 0) break;
+    for (int a = 0; a < nf; ++a) if (Hm[fr[a] * nv + fr[a]] > hmax) hmax = Hm[fr[a] * nv + fr[a]];
+    for (int r = 0; r < m; ++r) {
+      double t = 0.;
+      for (int a = 0; a < nf; ++a) t += Cj[r * nv + fr[a]] * Cj[r * nv + fr[a]];
+      if (t > cmax) cmax = t;
+    }
+    const double rho = cmax > 0. ? qp_rho * hmax / cmax : 0.;
+    for (int a = 0; a < nf; ++a)
+      for (int b = 0; b <= a; ++b) {
+        double t = Hm[fr[a] * nv + fr[b]];
+        for (int r = 0; r < m; ++r) t += rho * Cj[r * nv + fr[a]] * Cj[r * nv + fr[b]];
+        H[a * nf + b] = t;
+      }
+    if (!cholesky(H, nf, nf)) { ok = 0; break; }
+    for (int a = 0; a < nf; ++a) w[a] = gq[fr[a]];
+    chol_solve(H, nf, nf, w);
+    for (int r = 0; r < m; ++r) {
+      for (int a = 0; a < nf; ++a) Y[r * nf + a] = Cj[r * nv + fr[a]];
+      chol_solve(H, nf, nf, Y + r * nf);
+    }
+    {
+      double tr = 0.;
+      for (int r = 0; r < m; ++r) {
+        for (int s = 0; s <= r; ++s) {
+          double t = 0.;
+          for (int a = 0; a < nf; ++a) t += Cj[r * nv + fr[a]] * Y[s * nf + a];
+          Sc[r * m + s] = t;
+        }
+        double t = 0.;
+        for (int a = 0; a < nf; ++a) t -= Cj[r * nv + fr[a]] * w[a];
+        mult[r] = t;
+        tr += Sc[r * m + r];
+      }
+      for (int r = 0; r < m; ++r) Sc[r * m + r] += 1e-14 * tr + 1e-300;
+      if (!(tr > 0.) || !cholesky(Sc, m, m)) memset(mult, 0, sizeof(double) * MAXC);
+      else chol_solve(Sc, m, m, mult);
+    }
+    /* p = -H'^-1 (gq + C^T mult); the ratio test along p: the first variable to reach a bound */
+    double alpha = 1., pmax = 0.;
+    int blocking = -1;
+    for (int a = 0; a < nf; ++a) {
+      const int i = fr[a];
+      double t = w[a];
+      for (int r = 0; r < m; ++r) t += Y[r * nf + a] * mult[r];
+      p[a] = -t;
+      const double room = p[a] < 0. ? (lo[i] - v[i]) - d[i] : (hi[i] - v[i]) - d[i];
+      const double rel = fabs(p[a]) / (fabs(v[i]) + 1.);
+      if (rel > pmax) pmax = rel;
+      if (p[a] != 0.) {
+        const double ratio = room / p[a];
+        if (ratio < alpha) { alpha = ratio; blocking = a; }
+      }
+    }
+    if (alpha < 0.) alpha = 0.;
+    if (pmax > 1e-15) {
+      for (int a = 0; a < nf; ++a) d[fr[a]] += alpha * p[a];
+      if (blocking >= 0) {
+        const int i = fr[blocking];
+        held[i] = p[blocking] < 0. ? -1 : 1;
+        d[i] = (held[i] < 0 ? lo[i] : hi[i]) - v[i];
+        continue;
+      }
+      for (int i = 0; i < nv; ++i) {   /* gradient of the model at the new d */
+        double t = g[i];
+        for (int j = 0; j < nv; ++j) t += Hm[i * nv + j] * d[j];
+        gq[i] = t;
+      }
+    }
+    /* a minimiser on this working set: does a held variable want to leave its bound?  (mult: the
+     * multipliers of the equality constraints at this point -- C p = 0, so the rho term is 0) */
+    {
+      int worst = -1;
+      double wv = 0.;
+      for (int i = 0; i < nv; ++i) {
+        if (!held[i] || !(lo[i] < hi[i])) continue;
+        double s = gq[i], sc = fabs(gq[i]);
+        for (int r = 0; r < m; ++r) { s += Cj[r * nv + i] * mult[r]; sc += fabs(Cj[r * nv + i] * mult[r]); }
+        const double viol = held[i] < 0 ? -s : s;   /* > 0: the model falls when the variable moves inward */
+        if (viol > 1e-10 * sc + 1e-300 && viol > wv) { wv = viol; worst = i; }
+      }
+      if (worst < 0 || released >= nv) break;
+      held[worst] = 0;
+      ++released;
+    }
+  }
+  free(H); free(gq); free(w); free(p); free(Y); free(fr);
+  return ok;
+}
+
 /* One solver run (one re-window round).  Unconstrained clusters: bounded Levenberg-Marquardt
  * with an active set for the box.  Constrained clusters (dimer / trimer / tetramer): the same
  * iteration as a FEASIBLE-POINT method -- every iterate lies on the constraint manifold: the
@@ -634,12 +763,21 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
    * (the default modes); otherwise the model Hessian is J^T J throughout */
   int newton = use_newton && c->p->modes[1] == CTR_MODE_VAR;
   for (int a = 0; a < c->L.nd; ++a) newton = newton && c->p->modes[2 + a] == CTR_MODE_VAR;
+  /* fullq: the second-order part in ALL variables (full_second_order) instead */
+  int fullq = 0;
+  if (use_newton && full_q_mode && (full_q_mode == 2 || m)) {
+    int sizevar = 0;
+    for (int k2 = 2 + c->L.nd; k2 < c->L.np; ++k2) if (c->L.var_of[k2] >= 0) sizevar = 1;
+    if (!newton || sizevar) { fullq = 1; newton = 1; }
+  }
   double *H = malloc(sizeof(double) * nv * nv), *vt = malloc(sizeof(double) * nv);
   double *dl = malloc(sizeof(double) * nv), *w = malloc(sizeof(double) * nv);
   double *Y = malloc(sizeof(double) * nv * MAXC), *Cj = malloc(sizeof(double) * nv * MAXC);
   double *Cjt = malloc(sizeof(double) * nv * MAXC);
   int* fr = malloc(sizeof(int) * nv);
-  double cv[MAXC], cvt[MAXC], mult[MAXC], lam[MAXC], Sc[MAXC * MAXC];
+  int *inset = malloc(sizeof(int) * nv), *isfree = malloc(sizeof(int) * nv), *held = malloc(sizeof(int) * nv);
+  double *Hm = m ? malloc(sizeof(double) * nv * nv) : NULL;
+  double cv[MAXC], cvt[MAXC], mult[MAXC], lam[MAXC], lam_first[MAXC], Sc[MAXC * MAXC];
   double S, St, mu, nu = 2.;
   long P;
   int last_accepted = 1, it = 0;
@@ -654,12 +792,13 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
   memset(lam, 0, sizeof lam);
   memset(cv, 0, sizeof cv);
   /* the start vector need not satisfy the constraints: restore feasibility first */
-  if (m && !retract(c, v, lo, hi, cv, Cj, pair_of)) {
+  if (m && !retract(c, v, lo, hi, cv, Cj, pair_of, NULL)) {
     eval_cluster(c, v, &S, NULL, NULL, NULL, &P);
     out.P = P;
     goto done;
   }
-  eval_cluster(c, v, &S, g, A, newton ? Q : NULL, &P);
+  eval_cluster(c, v, &S, g, A, newton && !fullq ? Q : NULL, &P);
+  if (fullq) full_second_order(c, v, Q);
   out.P = P;
   if (P == 0 || !isfinite(S)) goto done;
   /* multiplies the Marquardt diagonal below.  With a size among the variables the first steps
@@ -678,29 +817,39 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
      * the ones that go with the minimum-norm retraction (g . n = lam^T C n for its normal
      * correction n), hence the ones whose curvature term makes the tangent-space model agree
      * with the objective along the retracted step to second order */
-    if (m) {
-      double tr = 0.;
-      for (int r = 0; r < m; ++r) {
-        for (int s = 0; s <= r; ++s) {
+    /* two passes: the multipliers over all variables the box does not fix give a first active
+     * set; the multipliers over the variables THAT leaves free (the ones a retraction with the
+     * held variables pinned goes with) give the active set used */
+    for (int pass = 0; pass < (m ? lam_passes : 1); ++pass) {
+      if (m) {
+        double tr = 0.;
+        for (int i = 0; i < nv; ++i) inset[i] = pass == 0 ? lo[i] < hi[i] : isfree[i];
+        for (int r = 0; r < m; ++r) {
+          for (int s = 0; s <= r; ++s) {
+            double t = 0.;
+            for (int i = 0; i < nv; ++i) if (inset[i]) t += Cj[r * nv + i] * Cj[s * nv + i];
+            Sc[r * m + s] = t;
+          }
           double t = 0.;
-          for (int i = 0; i < nv; ++i) if (lo[i] < hi[i]) t += Cj[r * nv + i] * Cj[s * nv + i];
-          Sc[r * m + s] = t;
+          for (int i = 0; i < nv; ++i) if (inset[i]) t -= Cj[r * nv + i] * g[i];
+          lam[r] = t;
+          tr += Sc[r * m + r];
         }
-        double t = 0.;
-        for (int i = 0; i < nv; ++i) if (lo[i] < hi[i]) t -= Cj[r * nv + i] * g[i];
-        lam[r] = t;
-        tr += Sc[r * m + r];
+        for (int r = 0; r < m; ++r) Sc[r * m + r] += 1e-14 * tr + 1e-300;
+        if (tr > 0. && cholesky(Sc, m, m)) chol_solve(Sc, m, m, lam);
+        else if (pass == 0) memset(lam, 0, sizeof lam);
+        else memcpy(lam, lam_first, sizeof lam);
+        if (pass == 0) memcpy(lam_first, lam, sizeof lam);
       }
-      for (int r = 0; r < m; ++r) Sc[r * m + r] += 1e-14 * tr + 1e-300;
-      if (tr > 0. && cholesky(Sc, m, m)) chol_solve(Sc, m, m, lam);
-      else memset(lam, 0, sizeof lam);
-    }
-    /* active set: fixed if at a bound and the Lagrangian gradient pushes outward */
-    for (int i = 0; i < nv; ++i) {
-      double gl = g[i];
-      for (int r = 0; r < m; ++r) gl += Cj[r * nv + i] * lam[r];
-      int fixed = (lo[i] == hi[i]) || (v[i] <= lo[i] && gl > 0.) || (v[i] >= hi[i] && gl < 0.);
-      if (!fixed) fr[nf++] = i;
+      /* active set: fixed if at a bound and the Lagrangian gradient pushes outward */
+      nf = 0;
+      for (int i = 0; i < nv; ++i) {
+        double gl = g[i];
+        for (int r = 0; r < m; ++r) gl += Cj[r * nv + i] * lam[r];
+        int fixed = (lo[i] == hi[i]) || (v[i] <= lo[i] && gl > 0.) || (v[i] >= hi[i] && gl < 0.);
+        isfree[i] = !fixed;
+        if (!fixed) fr[nf++] = i;
+      }
     }
     if (nf == 0) { out.ok = 1; break; }
     /* Model Hessian.  First choice: the exact one, J^T J + sum_p r_p d2r_p + sum_r mult_r d2c_r
@@ -731,6 +880,19 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
             B[(b + i1) * nv + b + i0] -= t;
           }
         }
+      }
+      int held_ok = 0;
+      if (m && cons_use_qp) {
+        /* constrained fit: the bound-constrained QP on the tangent space (cons_qp) */
+        memcpy(Hm, B, sizeof(double) * nv * nv);
+        for (int i = 0; i < nv; ++i) {
+          double d = A[i * nv + i];
+          Hm[i * nv + i] += mu * (d > 1e-300 ? d : 1.);
+          held[i] = isfree[i] ? 0 : (v[i] <= lo[i] ? -1 : 1);
+        }
+        if (!cons_qp(nv, m, Hm, g, Cj, v, lo, hi, held, dl, mult)) { if (trace > 2) fprintf(stderr, "   it %d attempt %d: QP matrix not PD (mu %g)\n", it, attempt, mu); continue; }
+        held_ok = 1;
+        goto have_step;
       }
       for (int a = 0; a < nf; ++a) {
         for (int b = 0; b <= a; ++b) H[a * nf + b] = B[fr[a] * nv + fr[b]];
@@ -774,12 +936,21 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
           dl[fr[a]] = -t;
         }
       }
-      /* projected trial point, retracted onto the constraint manifold */
+    have_step:
+      /* projected trial point, retracted onto the constraint manifold (first with the variables
+       * the QP holds on their bounds pinned, so that they stay there) */
       for (int i = 0; i < nv; ++i) {
         double t = v[i] + dl[i];
         vt[i] = t < lo[i] ? lo[i] : (t > hi[i] ? hi[i] : t);
+        if (held_ok && held[i] && lo[i] < hi[i]) vt[i] = held[i] < 0 ? lo[i] : hi[i];
       }
-      if (m && !retract(c, vt, lo, hi, cvt, Cjt, pair_of_t)) { if (trace > 2) fprintf(stderr, "   it %d attempt %d: retraction failed\n", it, attempt); continue; }
+      if (m && held_ok) {
+        memcpy(w, vt, sizeof(double) * nv);
+        if (retract(c, vt, lo, hi, cvt, Cjt, pair_of_t, held)) goto retracted;
+        memcpy(vt, w, sizeof(double) * nv);
+      }
+      if (m && !retract(c, vt, lo, hi, cvt, Cjt, pair_of_t, NULL)) { if (trace > 2) fprintf(stderr, "   it %d attempt %d: retraction failed\n", it, attempt); continue; }
+    retracted:;
       double gd = 0., dAd = 0.;
       stepmax = 0.;
       for (int i = 0; i < nv; ++i) {
@@ -831,7 +1002,8 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
       if (mu > 1e30) break;
       continue;
     }
-    eval_cluster(c, vt, &St, gt, At, newton ? Qt : NULL, &P);
+    eval_cluster(c, vt, &St, gt, At, newton && !fullq ? Qt : NULL, &P);
+    if (fullq && isfinite(St)) full_second_order(c, vt, Qt);
     double act = 0.5 * (S - St);
     if (trace)
       fprintf(stderr, "it %3d nf %d S %.10g St %.10g mu %.2e pred %.3e act %.3e step %.2e mult0 %.3e\n",
@@ -874,6 +1046,7 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
 done:
   free(g); free(A); free(gt); free(At); free(H); free(vt); free(dl); free(w);
   free(Y); free(Cj); free(Cjt); free(fr); free(Q); free(Qt); free(B);
+  free(inset); free(isfree); free(held); free(Hm);
   return out;
 }
 

@@ -105,28 +105,34 @@ def is_solver_specific(name):
     return name.startswith('hard_cons_') or name.startswith('tetramer2d_')
 
 
-# (fixture, cluster id): the reference fits it, the engine's minimiser does not (cost NaN).
-#   hard_cons_dimer_bounds / 5: a dimer whose start positions are 1.1 px apart with position
-#     bounds of +-1.84 px and a bond length of 7.4 x 5.7 px: the feasible set is a sliver in
-#     the corner of the box (three of the four coordinates of the reference's solution sit on
-#     their bounds, cost 0.155).
-#   hard_cons_dimer_sizevar / 6: two start positions 0.3 px apart on one feature, free sizes:
-#     linear convergence (no second derivatives w.r.t. the sizes), iteration limit.
+# (fixture, cluster id): the reference fits it and the engine's minimiser returns NaN.  EMPTY since
+# round 3 (the step of a constrained fit is a bound-constrained QP on the tangent space, see
+# oracle/ctr_oracle.c:cons_qp); check_solver_specific fails on any cluster without a result.
+KNOWN_FAIL_HERE = set()
+# (fixture, cluster id): both minimisers CONVERGE, to different local minima of the same
+# multi-modal objective, and the reference's has the lower cost.  All are fits that the constraint
+# forces away from the data (cost 0.06-0.16, ten times a good fit's):
 #   hard_cons_trimer / 2: three features in a row, 11 px end to end, forced into a triangle of
-#     6.2 px sides (cost 0.06 in the reference's default run; its converged run fails too).
-KNOWN_FAIL_HERE = {('hard_cons_dimer_bounds', 5), ('hard_cons_dimer_sizevar', 6),
-                   ('hard_cons_trimer', 2)}
-# (fixture, cluster id): ends in a minimum of higher cost than the reference's (poor fits:
-# the constraint contradicts the data)
-KNOWN_WORSE = {('hard_cons_trimer_sizecluster', 6), ('hard_cons_dimer_sizevar', 11)}
+#     6.2 px sides; the reference's default run ends in the mirrored triangle (cost 0.0624, here
+#     0.0712, quadratic convergence in every round); its converged run (tol 1e-14) fails.
+#   hard_cons_trimer_sizecluster / 6: the same geometry with a shared free size.
+#   hard_cons_dimer_sizevar / 11: a dimer on ONE real feature with free sizes: either start position
+#     takes the feature and the other becomes a 14 px blob (cost 0.075845 there, 0.075894 here).
+# On the random constrained set (tests/tools/check_vs_reference.py, 118 clusters) this happens in
+# both directions about equally often: 14 end higher here, 18 lower, 69 agree, 1 fails here only
+# (a 2D tetramer at the kink of constraints.py:102-114), 1 there only.  The list is strict: a
+# cluster named here that no longer ends higher fails the test (so the list cannot go stale).
+OTHER_MINIMUM = {('hard_cons_trimer', 2), ('hard_cons_trimer_sizecluster', 6),
+                 ('hard_cons_dimer_sizevar', 11)}
 
 
 def check_solver_specific(name, res, A, B, pos_columns):
     """Per-cluster comparison for the solver-specific fixtures.  For every cluster that the
     reference fits in at least one of its runs: the result here is finite, its cost is not
-    higher than the reference's best (both up to the documented exceptions above), and where
-    the costs agree the positions agree: within 5e-6 px of the converged run B, or -- when only
-    the default-tolerance run A exists -- within 1e-2 px of A (A stops at |dF| < 1e-6)."""
+    higher than the reference's best (up to the clusters of OTHER_MINIMUM, which must end
+    higher), and where the costs agree the positions agree: within 5e-6 px of the converged run
+    B, or -- when only the default-tolerance run A exists -- within 1e-2 px of A (A stops at
+    |dF| < 1e-6)."""
     n_checked = 0
     for cl, g in res.groupby('cluster'):
         a, b = A.loc[g.index], B.loc[g.index]
@@ -134,13 +140,15 @@ def check_solver_specific(name, res, A, B, pos_columns):
         finite = [x for x in (ca, cb) if x == x]
         if not finite:
             continue
+        assert co == co or (name, int(cl)) in KNOWN_FAIL_HERE, (name, cl, 'no result here', ca, cb)
         if co != co:
-            assert (name, int(cl)) in KNOWN_FAIL_HERE, (name, cl, 'no result here', ca, cb)
             continue
         best = min(finite)
+        listed = (name, int(cl)) in OTHER_MINIMUM
         if co > best * (1 + 1e-6):
-            assert (name, int(cl)) in KNOWN_WORSE, (name, cl, 'higher cost', co, best)
+            assert listed, (name, cl, 'higher cost', co, best)
             continue
+        assert not listed, (name, cl, 'listed as another minimum but ends at', co, 'reference', best)
         n_checked += 1
         if cb == cb and abs(co - cb) <= 1e-7 * cb:
             d = np.abs(g[pos_columns].values - b[pos_columns].values).max()
