@@ -76,90 +76,7 @@ def parse():
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 
 
-class Inbox(object):
-    """Rank 0's block for the result rows of every rank and step in flight, mapped by all ranks:
-    rows[world, nfl, pad_rows, width] f64, then seq[world, nfl] int64 (ctr_ipc_*, include/ctrefine.h)."""
-
-    def __init__(self, engine, base, world, nfl, pad_rows, width, owner):
-        self.engine, self.base, self.owner = engine, base, owner
-        self.world, self.nfl, self.pad_rows, self.width = world, nfl, pad_rows, width
-        self.seq_off = world * nfl * pad_rows * width * 8
-
-    @staticmethod
-    def n_bytes(world, nfl, pad_rows, width):
-        return world * nfl * pad_rows * width * 8 + world * nfl * 8
-
-    def rows_addr(self, r, slot):
-        return self.base + ((r * self.nfl + slot) * self.pad_rows) * self.width * 8
-
-    def seq_addr(self, r, slot):
-        return self.base + self.seq_off + (r * self.nfl + slot) * 8
-
-    def read_rows(self, r, slot, n):
-        return self.engine.ipc_read(self.rows_addr(r, slot), (n, self.width), np.float64)
-
-    def read_seq(self):
-        return self.engine.ipc_read(self.base + self.seq_off, (self.world, self.nfl), np.int64)
-
-    def release(self):
-        if self.base:
-            (self.engine.ipc_free if self.owner else self.engine.ipc_close)(self.base)
-            self.base = 0
-
-
-def open_inbox(torch, dist, engine, rank, world, nfl, pad_rows, width, coll_dev):
-    """Rank 0 allocates the inbox and hands its IPC handle round; every other rank maps it for
-    its own device and proves with a store FROM A KERNEL of that device that it can write there
-    (ctr_ipc_probe).  Returns (ok on every rank, Inbox); ok False -> the caller falls back to
-    the RCCL gather."""
-    ok, box, payload = True, None, [None]
-    pad_rows = max(pad_rows, 1)
-    try:
-        if os.environ.get('CTR_BENCH_NO_IPC'):     # (test switch: exercise the fallback)
-            raise RuntimeError("CTR_BENCH_NO_IPC is set")
-        if rank == 0:
-            base, handle = engine.ipc_alloc(Inbox.n_bytes(world, nfl, pad_rows, width))
-            box = Inbox(engine, base, world, nfl, pad_rows, width, owner=True)
-            payload = [handle]
-    except Exception as e:   # noqa: BLE001 (anything here means: no inbox)
-        sys.stderr.write("rank 0: cannot export the inbox (%r)\n" % (e,))
-        ok = False
-    dist.broadcast_object_list(payload, src=0)
-    if rank != 0:
-        try:
-            if payload[0] is None:
-                raise RuntimeError("rank 0 has no inbox")
-            box = Inbox(engine, engine.ipc_open(payload[0]), world, nfl, pad_rows, width, owner=False)
-            for slot in range(nfl):
-                engine.ipc_probe(box.seq_addr(rank, slot), -1 - rank)   # a peer store into rank 0's memory
-        except Exception as e:   # noqa: BLE001
-            sys.stderr.write("rank %d: cannot map or write rank 0's inbox (%r)\n" % (rank, e))
-            ok = False
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=coll_dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # (also orders the probes before rank 0's look)
-    ok = bool(flag.item())
-    if ok and rank == 0:
-        seq = box.read_seq()
-        ok = all((seq[r] == -1 - r).all() for r in range(1, world))
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=coll_dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    ok = bool(flag.item())
-    if not ok:
-        try:
-            if box is not None and rank != 0:
-                box.release()
-        except Exception:   # noqa: BLE001
-            pass
-        dist.barrier()          # importers first, then the owner
-        try:
-            if box is not None and rank == 0:
-                box.release()
-        except Exception:   # noqa: BLE001
-            pass
-        if rank == 0:
-            sys.stderr.write("bench: no IPC inbox, falling back to --transport rccl\n")
-        box = None
-    return ok, box
+from clustertracking_amd.parallel import Inbox, open_inbox   # noqa: E402  (the inbox is product code)
 
 
 def cpu_baseline(problem, host_batch):

@@ -7,7 +7,8 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
+IPC_HANDLE_BYTES = 128
 MAX_NDIM = 3
 MAX_NOISE_SIZE = 4.0
 MAX_PARAMS = 8
@@ -41,6 +42,7 @@ STATUS_TEXT = {
 
 FLAG_THROUGHPUT = 1   # ctr_problem.flags (include/ctrefine.h): scheduling hint, results unchanged
 FLAG_ISOLATE_TAIL = 2  # only the kernel of the likely slow fits beside the main stream
+FLAG_WINDOW_FILTER = 4  # noise_size was given: the window is thresholded even with every sigma 0
 
 
 class Problem(C.Structure):
@@ -113,6 +115,7 @@ def make_problem(ndim, isotropic, modes, radius, constraint=None, max_iter=10,
                 raise ValueError("noise_size must be between 0 and %g" % MAX_NOISE_SIZE)
             p.noise_size[i] = float(sgm)
         p.threshold = 0. if threshold is None else float(threshold)   # refine.py:38-39
+        p.flags |= FLAG_WINDOW_FILTER                                 # refine.py:37: `is not None`
     return p
 
 

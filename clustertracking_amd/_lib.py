@@ -218,16 +218,18 @@ class Engine(object):
 
     # ---- the inbox of a multi-GPU pipeline (include/ctrefine.h: ctr_ipc_*) ---------------------
     def ipc_alloc(self, n_bytes):
-        """(device pointer, 64-byte handle) of a zeroed block on this engine's device that other
-        processes can map."""
+        """(device pointer, handle blob) of a zeroed block on this engine's device that other
+        processes can map (the blob names the owning device, include/ctrefine.h)."""
         ptr = C.c_void_p()
-        handle = (C.c_ubyte * 64)()
+        handle = (C.c_ubyte * _abi.IPC_HANDLE_BYTES)()
         self._check(self._lib.ctr_ipc_alloc(self._h, C.c_int64(int(n_bytes)), C.byref(ptr), handle), 'ctr_ipc_alloc')
         return int(ptr.value), bytes(handle)
 
     def ipc_open(self, handle):
         ptr = C.c_void_p()
-        buf = (C.c_ubyte * 64).from_buffer_copy(handle)
+        if len(handle) != _abi.IPC_HANDLE_BYTES:
+            raise ValueError("an inbox handle has %d bytes" % _abi.IPC_HANDLE_BYTES)
+        buf = (C.c_ubyte * _abi.IPC_HANDLE_BYTES).from_buffer_copy(handle)
         self._check(self._lib.ctr_ipc_open(self._h, buf, C.byref(ptr)), 'ctr_ipc_open')
         return int(ptr.value)
 

@@ -356,6 +356,8 @@ int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
     if (p->modes[k2] == CTR_MODE_VAR) ++npf;
     else if (p->modes[k2] != CTR_MODE_CONST) ++nsh;
   }
+  // (noise_size given with every sigma 0: the reference's lowpass is then its threshold alone)
+  plan->lowpass = (p->flags & CTR_FLAG_WINDOW_FILTER) != 0;
   for (int a = 0; a < p->ndim; ++a) plan->lowpass = plan->lowpass || p->noise_size[a] > 0.;
   // (the lowpass lives in its own instantiations of the block kernel: every cluster goes there)
   if (plan->lowpass) default_modes = false;
@@ -688,12 +690,20 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
 
 
 
-static_assert(sizeof(hipIpcMemHandle_t) == CTR_IPC_HANDLE_BYTES, "IPC handle size");
+// the exported blob: the HIP IPC handle, then the PCI bus id of the device that owns the block
+// (NUL-terminated) so that an importer can identify the owner BEFORE it maps or touches anything
+constexpr size_t IPC_BUSID_OFF = sizeof(hipIpcMemHandle_t);
+static_assert(IPC_BUSID_OFF + 32 <= CTR_IPC_HANDLE_BYTES, "IPC handle blob size");
 
 int ctr_ipc_alloc(ctr_handle* h, int64_t bytes, void** dev_ptr, unsigned char* handle_out) {
   if (!h || !dev_ptr || !handle_out || bytes <= 0) return CTR_ERR_INVALID;
   *dev_ptr = nullptr;
   HIP_TRY(h, hipSetDevice(h->device));
+  char busid[32] = {0};
+  if (hipDeviceGetPCIBusId(busid, (int)sizeof busid, h->device) != hipSuccess || busid[0] == 0) {
+    (void)hipGetLastError();
+    return fail(h, CTR_ERR_DEVICE, "cannot read the PCI bus id of this device (needed to export an inbox)");
+  }
   void* p = nullptr;
   if (hipMalloc(&p, (size_t)bytes) != hipSuccess) return fail(h, CTR_ERR_NOMEM, "cannot allocate the inbox");
   hipIpcMemHandle_t ih;
@@ -701,7 +711,9 @@ int ctr_ipc_alloc(ctr_handle* h, int64_t bytes, void** dev_ptr, unsigned char* h
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e == hipSuccess) e = hipIpcGetMemHandle(&ih, p);
   if (e != hipSuccess) { (void)hipFree(p); return fail(h, CTR_ERR_DEVICE, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e)); }
+  std::memset(handle_out, 0, CTR_IPC_HANDLE_BYTES);
   std::memcpy(handle_out, &ih, sizeof ih);
+  std::memcpy(handle_out + IPC_BUSID_OFF, busid, sizeof busid - 1);
   *dev_ptr = p;
   return CTR_OK;
 }
@@ -710,19 +722,36 @@ int ctr_ipc_open(ctr_handle* h, const unsigned char* handle, void** dev_ptr) {
   if (!h || !handle || !dev_ptr) return CTR_ERR_INVALID;
   *dev_ptr = nullptr;
   HIP_TRY(h, hipSetDevice(h->device));
+  // Who owns the block?  A kernel of THIS device will store there, and a store that faults can
+  // take the GPUs of the node down: the owner must be this device or one it has peer access to,
+  // established before anything is mapped.  An owner this process cannot resolve (not visible,
+  // malformed blob) counts as "no access": the caller falls back to the collective.
+  char busid[32];
+  std::memcpy(busid, handle + IPC_BUSID_OFF, sizeof busid);
+  busid[sizeof busid - 1] = 0;
+  int owner = -1;
+  if (busid[0] == 0 || hipDeviceGetByPCIBusId(&owner, busid) != hipSuccess || owner < 0) {
+    (void)hipGetLastError();
+    return fail(h, CTR_ERR_DEVICE, "the device that owns the block is not visible to this process");
+  }
+  if (owner != h->device) {
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, h->device, owner) != hipSuccess || !can) {
+      (void)hipGetLastError();
+      return fail(h, CTR_ERR_DEVICE, "no peer access from this device to the device that owns the block");
+    }
+  }
   hipIpcMemHandle_t ih;
   std::memcpy(&ih, handle, sizeof ih);
   void* p = nullptr;
   const hipError_t e = hipIpcOpenMemHandle(&p, ih, hipIpcMemLazyEnablePeerAccess);
   if (e != hipSuccess) return fail(h, CTR_ERR_DEVICE, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
-  // a kernel of this device will store there: refuse a block on a device it has no peer access to
-  // (a store that faults can take the GPUs of the node down; the caller falls back to RCCL)
+  // cross-check where the runtime can tell: the mapped pointer must belong to that owner
   hipPointerAttribute_t attr;
-  if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.device != h->device) {
-    int can = 0;
-    if (hipDeviceCanAccessPeer(&can, h->device, attr.device) != hipSuccess || !can) {
+  if (hipPointerGetAttributes(&attr, p) == hipSuccess) {
+    if (attr.device != owner) {
       (void)hipIpcCloseMemHandle(p);
-      return fail(h, CTR_ERR_DEVICE, "no peer access from this device to the device that owns the block");
+      return fail(h, CTR_ERR_DEVICE, "the mapped block does not belong to the device named in its handle");
     }
   } else {
     (void)hipGetLastError();

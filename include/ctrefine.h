@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CTR_ABI_VERSION 5
+#define CTR_ABI_VERSION 6
 #define CTR_MAX_NDIM 3
 #define CTR_MAX_PARAMS 8 /* background, signal, <=3 positions, <=3 sizes */
 #define CTR_MAX_VARS 127 /* optimiser variables per cluster of the on-chip kernels; larger clusters
@@ -66,7 +66,7 @@ enum { CTR_MODE_CONST = 0, CTR_MODE_VAR = 1, CTR_MODE_GLOBAL = 2, CTR_MODE_CLUST
  * exactly 2 / 3 / 4 features (constraints.py:32-34) */
 enum { CTR_CONS_NONE = 0, CTR_CONS_DIMER = 1, CTR_CONS_TRIMER = 2, CTR_CONS_TETRAMER = 3 };
 
-/* ctr_problem.flags.  Scheduling only: the results do not depend on them.
+/* ctr_problem.flags.  The first two are scheduling only: the results do not depend on them.
  * CTR_FLAG_THROUGHPUT: the caller keeps several batches in flight on one device (one handle
  * each); favour machine time per cluster over the latency of one batch -- pairs that are not
  * likely to be slow fits share a wavefront four at a time, larger 2D clusters run on the
@@ -77,8 +77,12 @@ enum { CTR_CONS_NONE = 0, CTR_CONS_DIMER = 1, CTR_CONS_TRIMER = 2, CTR_CONS_TETR
  * does not share with the main stream of another handle (a queue is served in order: a long
  * kernel in front of a main stream delays that handle's whole next batch).  Costs 10-15 % on
  * batches without such a fit, gains 30 % on batches with one; a caller can time
- * both.  Assumes 2 hardware queues per handle (GPU_MAX_HW_QUEUES = 2 x handles in flight). */
-enum { CTR_FLAG_THROUGHPUT = 1, CTR_FLAG_ISOLATE_TAIL = 2 };
+ * both.  Assumes 2 hardware queues per handle (GPU_MAX_HW_QUEUES = 2 x handles in flight).
+ * CTR_FLAG_WINDOW_FILTER (NOT a scheduling flag): `noise_size` was given (refine.py:37 `if
+ *   noise_size is not None`): the window goes through the reference's lowpass even where every
+ *   sigma is 0 -- then that is its threshold alone, values <= threshold become 0
+ *   (preprocessing.py:41-49).  Implied by any noise_size > 0. */
+enum { CTR_FLAG_THROUGHPUT = 1, CTR_FLAG_ISOLATE_TAIL = 2, CTR_FLAG_WINDOW_FILTER = 4 };
 
 /* per-cluster status */
 enum {
@@ -258,15 +262,19 @@ int ctr_synchronize(ctr_handle* h, void* hip_stream);
  * allocates a block on its device and exports it; every other rank maps it and passes addresses
  * inside it as ctr_batch.result_rows / done_flag, so that the rows travel as peer stores over xGMI
  * while they are written -- no collective per batch (bench.py:open_inbox is the worked example).
- *   ctr_ipc_alloc: hipMalloc of `bytes` zeroed bytes on the handle's device + its IPC handle
- *     (CTR_IPC_HANDLE_BYTES bytes, to be sent to the other processes by any means).
+ *   ctr_ipc_alloc: hipMalloc of `bytes` zeroed bytes on the handle's device + a blob of
+ *     CTR_IPC_HANDLE_BYTES bytes to be sent to the other processes by any means: the HIP IPC
+ *     handle followed by the PCI bus id of the owning device (ABI 6).
  *   ctr_ipc_open: maps such a block into this process for the handle's device
- *     (hipIpcOpenMemHandle with lazy peer access, called with that device current).
+ *     (hipIpcOpenMemHandle with lazy peer access, called with that device current).  The owner
+ *     named in the blob must be this device or one it has peer access to (hipDeviceCanAccessPeer),
+ *     checked BEFORE anything is mapped; an owner this process cannot resolve is refused
+ *     (CTR_ERR_DEVICE): the caller then gathers with a collective instead.
  *   ctr_ipc_probe: stores `value` at `dst` (8 bytes) FROM A KERNEL of the handle's device and
  *     waits for it: proves at set-up time that this device can write the mapped block.
  *   ctr_ipc_read: copies `bytes` from device / mapped memory to the host (blocking).
  *   ctr_ipc_close / ctr_ipc_free: unmap (importer) / release (owner, after every importer closed). */
-#define CTR_IPC_HANDLE_BYTES 64
+#define CTR_IPC_HANDLE_BYTES 128
 int ctr_ipc_alloc(ctr_handle* h, int64_t bytes, void** dev_ptr, unsigned char* handle_out);
 int ctr_ipc_open(ctr_handle* h, const unsigned char* handle, void** dev_ptr);
 int ctr_ipc_probe(ctr_handle* h, void* dst, int64_t value);

@@ -163,6 +163,7 @@ void ctro_lowpass(int nd, const int* wshape, const double* noise_size, double th
 }
 
 static int has_lowpass(const ctr_problem* p) {
+  if (p->flags & CTR_FLAG_WINDOW_FILTER) return 1;   /* refine.py:37: noise_size is not None */
   for (int a = 0; a < p->ndim; ++a)
     if (p->noise_size[a] > 0.) return 1;
   return 0;

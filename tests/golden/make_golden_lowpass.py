@@ -22,7 +22,7 @@ import make_golden as mg  # noqa: E402  (loads the reference through oracle/refs
 from clustertracking_amd import artificial  # noqa: E402
 
 
-def main():
+def main(only=None):
     # 2D, noisy, sigma 1 on both axes (the usual choice); features near the frame edge too
     im, truth, p0 = artificial.random_frame((200, 240), 60, 3., 100, 12, 41, margin=8)
     mg.save_case('lowpass_2d', mg.table(p0, 3., 90., 6., 2, True), im[None],
@@ -34,6 +34,14 @@ def main():
     # free sizes (the lowpass widens the features)
     mg.save_case('lowpass_2d_sizevar', mg.table(p0, 4.3, 150., 8., 2, True), im[None],
                  dict(diameter=17, noise_size=1, param_mode=dict(size='var')))
+    # noise_size given as 0: the reference's lowpass is then its threshold alone
+    # (refine.py:37 `is not None`, preprocessing.py:41-49) -- CTR_FLAG_WINDOW_FILTER
+    if only in (None, 'lowpass_threshold_only'):
+        im2, truth2, p02 = artificial.random_frame((120, 140), 24, 3., 120, 14, 44, margin=10)
+        mg.save_case('lowpass_threshold_only', mg.table(p02, 3., 100., 0., 2, True), im2[None],
+                     dict(diameter=13, noise_size=0, threshold=25))
+        if only is not None:
+            return
     # 3D anisotropic
     im, truth, p0 = artificial.random_frame((24, 56, 56), 8, (2., 4., 4.), 100, 10, 43,
                                             margin=(5, 9, 9))
@@ -42,4 +50,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else None)

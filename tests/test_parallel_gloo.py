@@ -24,6 +24,34 @@ def test_frame_blocks_partition():
         assert max(lens) - min(lens) <= 1
 
 
+def test_frame_blocks_balanced_by_weight():
+    """blocks balanced by feature count when the frames are uneven -- contiguous,
+    a partition, and no rank more than one frame's weight away from its share."""
+    rng = np.random.RandomState(3)
+    per_frame = rng.randint(1, 400, 57)
+    per_frame[10] = 3000                      # one frame as heavy as ten others
+    frames = np.repeat(np.arange(57) * 2 + 5, per_frame)   # (frame numbers need not start at 0)
+    for world in (1, 2, 3, 8):
+        blocks = [parallel.frame_block(frames, world, r, np.ones(len(frames))) for r in range(world)]
+        assert_equal(np.concatenate(blocks), np.unique(frames))
+        share = len(frames) / world
+        for b in blocks:
+            assert abs(np.isin(frames, b).sum() - share) <= per_frame.max()
+        # the same cut on every rank whatever the row order
+        perm = rng.permutation(len(frames))
+        again = [parallel.frame_block(frames[perm], world, r, np.ones(len(frames))) for r in range(world)]
+        for a, b in zip(blocks, again):
+            assert_equal(a, b)
+    # equal weights per frame = the plain split up to rounding of the cut positions
+    even = np.repeat(np.arange(12), 7)
+    lens = [len(parallel.frame_block(even, 4, r, np.ones(len(even)))) for r in range(4)]
+    assert lens == [3, 3, 3, 3]
+    # likely slow fits weigh more: two start positions 0.5 px apart
+    f = pd.DataFrame(dict(frame=[0, 0, 0, 1, 1, 1], y=[10., 10.4, 30., 10., 20., 30.], x=[10., 10.3, 30., 10., 20., 30.]))
+    w = parallel.shard_weights(f, ['y', 'x'], (6, 6), slow_fit_weight=50.)
+    assert_equal(w, [51., 51., 1., 1., 1., 1.])
+
+
 def _video(n_frames=5):
     frames, tabs = [], []
     for t in range(n_frames):
