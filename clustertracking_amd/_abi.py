@@ -11,7 +11,7 @@ ABI_VERSION = 6
 IPC_HANDLE_BYTES = 128
 MAX_NDIM = 3
 MAX_NOISE_SIZE = 4.0
-MAX_PARAMS = 8
+MAX_PARAMS = 9
 MAX_VARS = 127
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NOMEM = range(5)
@@ -19,7 +19,9 @@ OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NOMEM = range(5)
 DTYPE_CODES = {np.dtype(np.uint8): 0, np.dtype(np.uint16): 1, np.dtype(np.int16): 2,
                np.dtype(np.int32): 3, np.dtype(np.float32): 4, np.dtype(np.float64): 5}
 
-FIT_GAUSS = 0
+FIT_GAUSS, FIT_RING, FIT_DISC, FIT_INV_SERIES = 0, 1, 2, 3
+FIT_CODES = {'gauss': FIT_GAUSS, 'ring': FIT_RING, 'disc': FIT_DISC}
+FIT_EXTRAS = {FIT_GAUSS: 0, FIT_RING: 1, FIT_DISC: 1}   # profile parameters after the sizes
 MODE_CONST, MODE_VAR, MODE_GLOBAL, MODE_CLUSTER = 0, 1, 2, 3
 CONS_NONE, CONS_DIMER, CONS_TRIMER, CONS_TETRAMER = 0, 1, 2, 3
 CONS_CODES = {None: 0, 'dimer': 1, 'trimer': 2, 'tetramer': 3}
@@ -83,14 +85,17 @@ class Synth(C.Structure):
 
 def make_problem(ndim, isotropic, modes, radius, constraint=None, max_iter=10,
                  max_shift=1., max_rms_dev=1., residual_factor=100000.,
-                 solver_maxiter=100, xtol=0., ftol=0., noise_size=None, threshold=None):
+                 solver_maxiter=100, xtol=0., ftol=0., noise_size=None, threshold=None,
+                 fit_function='gauss'):
     """Fill a ``ctr_problem``.  ``constraint`` = None or (kind, dist[ndim]); ``noise_size`` = None
     or one sigma per axis (refine.py:37-40)."""
     p = Problem()
     p.ndim = int(ndim)
     p.isotropic = int(bool(isotropic))
-    p.fit_function = FIT_GAUSS
-    p.n_params = 2 + ndim + (1 if isotropic else ndim)
+    if fit_function not in FIT_CODES:
+        raise ValueError("fit_function must be one of %s" % sorted(FIT_CODES))
+    p.fit_function = FIT_CODES[fit_function]
+    p.n_params = 2 + ndim + (1 if isotropic else ndim) + FIT_EXTRAS[p.fit_function]
     if len(modes) != p.n_params:
         raise ValueError("modes must have %d entries" % p.n_params)
     for i, m in enumerate(modes):

@@ -48,6 +48,47 @@ def draw_gaussian(image, position, size, max_value):
     return image
 
 
+def feat_ring(r, ndim, thickness):
+    """Ring with a Gaussian cross-section (reference artificial.py:17-19)."""
+    return np.exp(((r - 1 + thickness) / thickness) ** 2 * ndim / -2)
+
+
+def feat_disc(r, ndim, disc_size):
+    """Solid disc with Gaussian-smoothed border (reference artificial.py:22-28, ``feat_hat``)."""
+    result = np.ones_like(r)
+    mask = r > disc_size
+    result[mask] = np.exp(((r[mask] - disc_size) / (1 - disc_size)) ** 2 * ndim / -2)
+    return result
+
+
+def draw_feature(image, position, size, max_value, feat_func='gauss', **kwargs):
+    """Add one radially symmetric feature in place: the reference's ``draw_feature``
+    (artificial.py:81-141; patch of 8 x size per axis, ``r = sqrt(sum(((idx - c)/size)^2))``, the
+    spot truncated to the image dtype and added with integer wrap-around) for ``feat_func`` =
+    'gauss', 'ring' (``thickness=``) or 'disc' (``disc_size=``)."""
+    if feat_func == 'gauss':
+        return draw_gaussian(image, position, size, max_value)
+    func = dict(ring=feat_ring, disc=feat_disc)[feat_func]
+    ndim = image.ndim
+    size = _as_tuple(size, ndim)
+    sl = []
+    r2 = 0.
+    for ax, (c, s, lim) in enumerate(zip(position, size, image.shape)):
+        if c >= lim or c < 0:
+            raise ValueError("Position outside of image.")
+        lo = max(int(np.floor(c - 4. * s)), 0)
+        hi = min(int(np.ceil(c + 4. * s + 1)), lim)
+        sl.append(slice(lo, hi))
+        t = (np.arange(lo, hi, dtype=np.float64) - c) / s
+        shape = [1] * ndim
+        shape[ax] = -1
+        r2 = r2 + (t * t).reshape(shape)
+    spot = max_value * func(np.sqrt(r2), ndim=ndim, **kwargs)
+    with np.errstate(over='ignore'):
+        image[tuple(sl)] += spot.astype(image.dtype)
+    return image
+
+
 def add_poisson_noise(image, level, rng, saturation=None):
     """Poisson noise then clip to the dtype range (artificial.py:368-378)."""
     if level <= 0:

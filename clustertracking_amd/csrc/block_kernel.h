@@ -253,13 +253,16 @@ __device__ unsigned long long g_stamps[16];
 // (it costs the unconstrained fits registers otherwise: 700 B of scratch per lane, measured).
 // LP: the instantiation for problems with a lowpass of the window (ctr_problem.noise_size): every
 // pixel value is the filtered one, computed from the raw frame where it is needed.
-template <int ND, bool ISO, int NT, int W, bool CONS, bool LP = false>
+// FIT: the radial profile (CTR_FIT_GAUSS / RING / DISC, device_common.h:profile_dev); ring and disc
+// carry one more parameter column (thickness / disc_size) and iterate with the Gauss-Newton model.
+template <int ND, bool ISO, int NT, int W, bool CONS, bool LP = false, int FIT = 0>
 __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
 #ifdef CTR_STAMPS
   unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
 #endif
   using SM = SmemB<NT, W, CONS>;
-  constexpr int NP = 2 + ND + (ISO ? 1 : ND);
+  constexpr int NX = FIT != CTR_FIT_GAUSS ? 1 : 0;    // profile parameters after the sizes
+  constexpr int NP = 2 + ND + (ISO ? 1 : ND) + NX;
   constexpr int NSZ = ISO ? 1 : ND;
   constexpr int LDC = SM::NVC;
   extern __shared__ double smem[];
@@ -290,7 +293,8 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
   const int m = CONS ? n_constraints(k.prob, n) : 0;
   // the exact second-order terms need signal and positions as per-feature variables (the
   // default modes); otherwise the model Hessian is J^T J throughout (same rule: oracle solve())
-  bool newton_on = L.slot[1] >= 0 && L.per_feat[1];
+  // (those terms are the gaussian's: the other profiles iterate with J^T J)
+  bool newton_on = FIT == CTR_FIT_GAUSS && L.slot[1] >= 0 && L.per_feat[1];
 #pragma unroll
   for (int a = 0; a < ND; ++a) newton_on = newton_on && L.slot[2 + a] >= 0 && L.per_feat[2 + a];
   const void* frame = (const char*)k.frames + (size_t)k.frame_index[cl] * k.frame_elems * dtype_size(k.frame_dtype);
@@ -320,7 +324,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
   // constrained fits with other than the default modes: the second-order part in ALL variables
   // (second_order_pass after every accepted step) instead of the (signal, position) part that
   // the pixel pass sums (same rule: oracle solve(), fullq)
-  const bool fullq = CONS && m != 0 && (!newton_on || size_is_var);
+  const bool fullq = CONS && FIT == CTR_FIT_GAUSS && m != 0 && (!newton_on || size_is_var);
   const bool cheapq = newton_on && !fullq;
   newton_on = newton_on || fullq;
   double* Qp = smem + SM::o_Qp;
@@ -329,6 +333,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
     for (int i = lane; i < n; i += WAVE) {
       double* f = fpar + i * FP;
       f[0] = par(vv, i, 1);
+      if (NX) f[13] = par(vv, i, NP - 1);   // the profile parameter
 #pragma unroll
       for (int a = 0; a < ND; ++a) {
         f[1 + a] = par(vv, i, 2 + a);
@@ -878,9 +883,9 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
         while (todo != 0ull) {
           const int i = __builtin_ctzll(todo);
           todo &= todo - 1ull;
-          double d[1 + ND + NSZ];
+          double d[1 + ND + NSZ + NX];
 #pragma unroll
-          for (int t = 0; t < 1 + ND + NSZ; ++t) d[t] = 0.;
+          for (int t = 0; t < 1 + ND + NSZ + NX; ++t) d[t] = 0.;
           bool in = false;
           if (valid && ((cand >> i) & 1ull)) {
             double rel[ND];
@@ -900,9 +905,23 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
               dd[a] = (double)(idx[a] + origin[a]) - f[1 + a];
               r2 += dd[a] * dd[a] * f[4 + a];
             }
-            const double gv = exp(-0.5 * ND * r2);  // fitfunc.py:112-118
             const double sig = f[0];
-            const double sdg = sig * (0.5 * ND) * gv;  // -signal * dg/dr2
+            double gv, sdg;
+            if constexpr (FIT == CTR_FIT_GAUSS) {
+              gv = exp(-0.5 * ND * r2);  // fitfunc.py:112-118
+              sdg = sig * (0.5 * ND) * gv;  // -signal * dg/dr2
+            } else {
+              double qraw = 0., dg, dge;
+#pragma unroll
+              for (int a = ND - 1; a >= 0; --a) qraw += dd[a] * dd[a];
+              profile_dev<FIT, ND>(r2, f[13], gv, dg, dge);
+              // r2_*_safe (fitfunc.py:20-26,...): no value within one pixel of the centre; the
+              // pixel is skipped like a NaN pixel of the image (it still counts in P)
+              // (the disc has the value 1 there: its function only overwrites where r2 > disc_size^2)
+              if (qraw < 1.) { gv = (FIT == CTR_FIT_DISC && f[13] > 0.) ? 1. : NAN; dg = 0.; dge = 0.; }
+              sdg = -sig * dg;
+              d[1 + ND + NSZ] = -sig * dge;   // fitfunc.py:480-481
+            }
             res -= sig * gv;
             d[0] = -gv;
             double q2 = 0.;
@@ -1649,7 +1668,7 @@ __global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
       // sum_p res_p d2res_p/dv dv in ALL variables is summed here in one more pass over the
       // window (oracle: full_second_order), whatever the parameter modes.
       double* sd = vt;   // (free now)
-      bool pd = ok && n > 0;
+      bool pd = ok && n > 0 && FIT == CTR_FIT_GAUSS;   // (the second derivatives are the gaussian's)
       if (pd) {
         for (int e = lane; e < tri(nv); e += WAVE) {
           int a = (int)((sqrt(8. * e + 1.) - 1.) * 0.5);

@@ -106,6 +106,10 @@ struct ctr_handle {
   small_fn small_bulk2[2][2];     // pairs with 16 lanes per cluster (the bulk of a pairs bin)
   KernelInfo lp[2][2][MAXNT];     // block kernel with the lowpass of the window: [ndim-2][iso][nt-1]
   KernelInfo lp_cons[2][2][2];    // ... for constrained clusters, nt = 1, 2
+  KernelInfo fit[2][2][2][MAXNT]; // ring / disc profiles: [fit-1][ndim-2][iso][nt-1]
+  KernelInfo fit_cons[2][2][2][2];
+  bool fit_attr[2][2][2][MAXNT] = {};
+  bool fit_cons_attr[2][2][2][2] = {};
   bool lp_attr[2][2][MAXNT] = {};
   bool lp_cons_attr[2][2][2] = {};
   KernelInfo large[2][2][2];      // refine_large_kernel<ndim, iso, lowpass>
@@ -134,11 +138,13 @@ int fail(ctr_handle* h, int code, const std::string& msg) {
 int validate(const ctr_problem* p, std::string& msg) {
   if (!p) { msg = "null problem"; return CTR_ERR_INVALID; }
   if (p->ndim != 2 && p->ndim != 3) { msg = "ndim must be 2 or 3"; return CTR_ERR_INVALID; }
-  if (p->fit_function != CTR_FIT_GAUSS) {
-    msg = "only the gauss fit function is implemented";
+  if (p->fit_function != CTR_FIT_GAUSS && p->fit_function != CTR_FIT_RING && p->fit_function != CTR_FIT_DISC) {
+    msg = "fit function not implemented (gauss, ring and disc are)";
     return (p->fit_function >= 0 && p->fit_function <= CTR_FIT_INV_SERIES) ? CTR_ERR_UNSUPPORTED : CTR_ERR_INVALID;
   }
-  const int np = 2 + p->ndim + (p->isotropic ? 1 : p->ndim);
+  const bool other_profile = p->fit_function != CTR_FIT_GAUSS;
+  // ring: 'thickness', disc: 'disc_size' -- one more column after the sizes (fitfunc.py:195-204)
+  const int np = 2 + p->ndim + (p->isotropic ? 1 : p->ndim) + (other_profile ? 1 : 0);
   if (p->n_params != np) { msg = "n_params does not match ndim/isotropic"; return CTR_ERR_INVALID; }
   for (int k = 0; k < np; ++k) {
     const int m = p->modes[k];
@@ -160,6 +166,11 @@ int validate(const ctr_problem* p, std::string& msg) {
       return CTR_ERR_INVALID;
     }
   if (p->threshold != p->threshold) { msg = "threshold is NaN"; return CTR_ERR_INVALID; }
+  if (other_profile) {
+    bool lp = (p->flags & CTR_FLAG_WINDOW_FILTER) != 0;
+    for (int a = 0; a < p->ndim; ++a) lp = lp || p->noise_size[a] > 0.;
+    if (lp) { msg = "noise_size together with the ring / disc profiles is not implemented"; return CTR_ERR_UNSUPPORTED; }
+  }
   return CTR_OK;
 }
 
@@ -303,6 +314,10 @@ int ctr_create(ctr_handle** out, int device) {
         const KernelInfo t = di == 0 ? ctr_block_kernel_2d(ii, nt, 1, 0) : ctr_block_kernel_3d(ii, nt, 1, 0);
         h->lp[di][ii][nt - 1] = ctr_block_kernel_lp(2 + di, ii, nt, 0);
         if (nt <= 2) h->lp_cons[di][ii][nt - 1] = ctr_block_kernel_lp(2 + di, ii, nt, 1);
+        for (int fi = 0; fi < 2; ++fi) {
+          h->fit[fi][di][ii][nt - 1] = di == 0 ? ctr_block_kernel_fit2d(ii, nt, 0, fi + 1) : ctr_block_kernel_fit3d(ii, nt, 0, fi + 1);
+          if (nt <= 2) h->fit_cons[fi][di][ii][nt - 1] = di == 0 ? ctr_block_kernel_fit2d(ii, nt, 1, fi + 1) : ctr_block_kernel_fit3d(ii, nt, 1, fi + 1);
+        }
         if (nt <= 2)
           for (int tp = 0; tp < 2; ++tp)
             h->cons[di][ii][tp][nt - 1] = di == 0 ? ctr_block_kernel_2d(ii, nt, tp, 1) : ctr_block_kernel_3d(ii, nt, tp, 1);
@@ -361,6 +376,9 @@ int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
   for (int a = 0; a < p->ndim; ++a) plan->lowpass = plan->lowpass || p->noise_size[a] > 0.;
   // (the lowpass lives in its own instantiations of the block kernel: every cluster goes there)
   if (plan->lowpass) default_modes = false;
+  // (so do the ring / disc profiles; clusters beyond the block kernel get status 5 there)
+  const bool other_profile = p->fit_function != CTR_FIT_GAUSS;
+  if (other_profile) default_modes = false;
   std::vector<long long> ws_off((size_t)n_clusters, 0);
   long long ws_total = 0;
   for (int64_t c = 0; c < n_clusters; ++c) {
@@ -381,10 +399,11 @@ int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
       bin = nt > MAXNT ? BIN_LARGE : (nt < 1 ? 0 : nt - 1);
       if (bin < MAXNT && n > (16 * (bin + 1) < MAXF ? 16 * (bin + 1) : MAXF)) bin = BIN_LARGE;
       if (any_cons && bin < 2) bin = bin == 0 ? BIN_CONS1 : BIN_CONS2;   // (at most 29 variables)
+      else if (any_cons && bin < MAXNT) bin = BIN_TOO_LARGE;             // (ring / disc with every column free)
     }
     if (bin == BIN_LARGE) {
       // the large kernel's 16-column row: [r, shared.., own.., r_o, shared_o..]
-      if (npf < 1 || 2 + 2 * nsh + npf > 16) bin = BIN_TOO_LARGE;
+      if (npf < 1 || 2 + 2 * nsh + npf > 16 || other_profile) bin = BIN_TOO_LARGE;
       else {
         ws_off[(size_t)c] = ws_total;
         ws_total += large_ws((int)n, npf, nsh).total;
@@ -553,10 +572,11 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     // (2D only: a 3D window has thousands of pixels, more wavefronts per cluster pay there)
     const bool tp = (p.flags & CTR_FLAG_THROUGHPUT) != 0 && p.ndim == 2;
     const bool lpk = plan->lowpass;
-    kernel_fn fn = lpk ? h->lp[di][ii][bin].fn : (tp ? h->table_tp[di][ii][bin] : h->table[di][ii][bin]);
-    const size_t bytes = lpk ? h->lp[di][ii][bin].smem : (tp ? h->smem_bytes_tp[di][ii][bin] : h->smem_bytes[di][ii][bin]);
-    const int threads = lpk ? h->lp[di][ii][bin].threads : (tp ? h->block_threads_tp[di][ii][bin] : h->block_threads[di][ii][bin]);
-    bool& attr = lpk ? h->lp_attr[di][ii][bin] : (tp ? h->attr_set_tp[di][ii][bin] : h->attr_set[di][ii][bin]);
+    const int fi = p.fit_function - 1;   // >= 0: ring / disc
+    kernel_fn fn = fi >= 0 ? h->fit[fi][di][ii][bin].fn : lpk ? h->lp[di][ii][bin].fn : (tp ? h->table_tp[di][ii][bin] : h->table[di][ii][bin]);
+    const size_t bytes = fi >= 0 ? h->fit[fi][di][ii][bin].smem : lpk ? h->lp[di][ii][bin].smem : (tp ? h->smem_bytes_tp[di][ii][bin] : h->smem_bytes[di][ii][bin]);
+    const int threads = fi >= 0 ? h->fit[fi][di][ii][bin].threads : lpk ? h->lp[di][ii][bin].threads : (tp ? h->block_threads_tp[di][ii][bin] : h->block_threads[di][ii][bin]);
+    bool& attr = fi >= 0 ? h->fit_attr[fi][di][ii][bin] : lpk ? h->lp_attr[di][ii][bin] : (tp ? h->attr_set_tp[di][ii][bin] : h->attr_set[di][ii][bin]);
     if (!attr) {
       HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
       attr = true;
@@ -573,8 +593,9 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     const int64_t cnt = plan->bin_count[bin];
     if (cnt == 0) continue;
     const int tp = ((p.flags & CTR_FLAG_THROUGHPUT) != 0 && p.ndim == 2) ? 1 : 0;
-    const KernelInfo& ki = plan->lowpass ? h->lp_cons[di][ii][cb] : h->cons[di][ii][tp][cb];
-    bool& cattr = plan->lowpass ? h->lp_cons_attr[di][ii][cb] : h->cons_attr[di][ii][tp][cb];
+    const int fi = p.fit_function - 1;   // >= 0: ring / disc
+    const KernelInfo& ki = fi >= 0 ? h->fit_cons[fi][di][ii][cb] : plan->lowpass ? h->lp_cons[di][ii][cb] : h->cons[di][ii][tp][cb];
+    bool& cattr = fi >= 0 ? h->fit_cons_attr[fi][di][ii][cb] : plan->lowpass ? h->lp_cons_attr[di][ii][cb] : h->cons_attr[di][ii][tp][cb];
     if (!cattr) {
       HIP_TRY(h, hipFuncSetAttribute(ki.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ki.smem));
       cattr = true;

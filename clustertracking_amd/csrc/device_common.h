@@ -118,6 +118,45 @@ __device__ __forceinline__ double wave_sum4(double v0, double v1, double v2, dou
   return row_sum(kk);
 }
 
+// Radial profiles (fitfunc.py:112-146; oracle/ctr_oracle.c:profile, same operations in the same
+// order): value g(r2; e), dg/dr2 and dg/de with e the profile parameter (ring: 'thickness',
+// disc: 'disc_size').  The disc's derivatives are the analytic ones of fitfunc.py:121-131 (the
+// reference differentiates numerically).
+template <int FIT, int ND>
+__device__ __forceinline__ void profile_dev(double r2, double e, double& g, double& dg_dr2, double& dg_de) {
+  if constexpr (FIT == CTR_FIT_RING) {
+    const double r = sqrt(r2), num = r - 1. + e;
+    const double f = exp(-0.5 * ND * ((num / e) * (num / e)));
+    g = f;
+    dg_dr2 = f * (-0.5 * ND / (r * (e * e))) * num;
+    dg_de = f * ND * (num * num / (e * e * e) - num / (e * e));
+  } else if constexpr (FIT == CTR_FIT_DISC) {
+    if (e > 0.) {
+      const bool clamped = e >= 1.;
+      const double ds = clamped ? 0.999 : e;
+      if (r2 > ds * ds) {
+        const double r = sqrt(r2), w = 1. - ds, u = (r - ds) / w;
+        const double f = exp(u * u * ND / -2.);
+        g = f;
+        dg_dr2 = f * (-(double)ND * u / w) / (2. * r);
+        dg_de = clamped ? 0. : f * (-(double)ND * u) * ((r - 1.) / (w * w));
+      } else {
+        g = r2 == r2 ? 1. : NAN;
+        dg_dr2 = 0.;
+        dg_de = 0.;
+      }
+    } else {
+      g = exp(-0.5 * ND * r2);
+      dg_dr2 = -0.5 * ND * g;
+      dg_de = 0.;
+    }
+  } else {
+    g = exp(-0.5 * ND * r2);
+    dg_dr2 = -0.5 * ND * g;
+    dg_de = 0.;
+  }
+}
+
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
 
 struct Layout {

@@ -69,7 +69,7 @@ __host__ __device__ inline LargeWs large_ws(int n, int npf, int ns) {
   W.nvp_i = (nn + 7) & ~7LL;
   long long o = 0;
   W.o_vec = o;  o += 14 * W.nvp;                 // v vt v0 lo hi g x r z p Ap dl Dm free
-  W.o_cur = o;  o += W.nvp_i * 8;                // parameter rows (CTR_MAX_PARAMS)
+  W.o_cur = o;  o += W.nvp_i * CTR_MAX_PARAMS;   // parameter rows
   W.o_mco = o;  o += W.nvp_i * 3 + 8;            // mask centres
   W.o_fpar = o; o += W.nvp_i * 14;               // derived per-feature constants (FP)
   W.o_pre = o;  o += W.nvp_i * 32;               // factors of the diagonal blocks
@@ -89,6 +89,9 @@ KernelInfo ctr_block_kernel_2d(int iso, int nt, int throughput, int cons);
 KernelInfo ctr_block_kernel_3d(int iso, int nt, int throughput, int cons);
 // the same with the lowpass of the window (LP = true); one instantiation per (ndim, iso, nt, cons)
 KernelInfo ctr_block_kernel_lp(int ndim, int iso, int nt, int cons);
+// ring / disc profiles (FIT = CTR_FIT_RING / CTR_FIT_DISC); cons: nt = 1..3
+KernelInfo ctr_block_kernel_fit2d(int iso, int nt, int cons, int fit);
+KernelInfo ctr_block_kernel_fit3d(int iso, int nt, int cons, int fit);
 // refine_small_kernel<ND, NF, ISO, SG>(KArgs, int* counter); nullptr if not instantiated
 const void* ctr_small_kernel(int ndim, int nf, int iso, int sg);
 KernelInfo ctr_large_kernel(int ndim, int iso, int lp);   // lp: with the lowpass of the window

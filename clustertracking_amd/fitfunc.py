@@ -18,6 +18,10 @@ MODE_DICT = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 5, 6: 6,
 
 # enum shared with include/ctrefine.h (CTR_FIT_*)
 FIT_FUNCTION_CODES = {'gauss': 0, 'ring': 1, 'disc': 2, 'inv_series': 3}
+# reference fitfunc.py:195-204 (function_templates) for the profiles the engine implements
+FIT_TEMPLATES = dict(gauss=dict(params=[], default={}, continuous=True),
+                     ring=dict(params=['thickness'], default=dict(thickness=0.5), continuous=False),
+                     disc=dict(params=['disc_size'], default=dict(disc_size=0.5), continuous=False))
 
 
 class FitFunctions(object):
@@ -25,8 +29,9 @@ class FitFunctions(object):
 
     Column order of the per-feature parameter matrix (reference
     fitfunc.py:353-354): ``[background, signal, (z,) y, x, size | size_(z,)y,x]``.
-    Only the Gaussian profile is implemented by the engine; the other
-    reference profiles are recognised and rejected with a clear message.
+    ``'ring'`` and ``'disc'`` add one profile parameter after the sizes (``thickness`` /
+    ``disc_size``, fitfunc.py:195-204); ``'inv_series_N'`` and custom functions are recognised
+    and rejected with a clear message.
     """
 
     def __init__(self, fit_function='gauss', ndim=2, isotropic=True,
@@ -35,21 +40,24 @@ class FitFunctions(object):
             raise NotImplementedError(
                 "custom (dict) fit functions need Python callbacks per "
                 "evaluation and are not supported by the MI355X engine")
-        if fit_function != 'gauss':
+        if fit_function not in FIT_TEMPLATES:
             base = fit_function.rsplit('_', 1)[0] if fit_function not in \
                 FIT_FUNCTION_CODES else fit_function
             if base in FIT_FUNCTION_CODES:
                 raise NotImplementedError(
-                    "fit_function %r is reserved in the C-ABI but not yet "
-                    "implemented by the MI355X engine (only 'gauss')" % fit_function)
+                    "fit_function %r is reserved in the C-ABI but not implemented by the MI355X "
+                    "engine ('gauss', 'ring' and 'disc' are)" % fit_function)
             raise ValueError("Unknown fit function {}".format(fit_function))
         self.fit_function = fit_function
         self.ndim = int(ndim)
         self.isotropic = bool(isotropic)
         self.pos_columns = default_pos_columns(ndim)
         self.size_columns = default_size_columns(ndim, isotropic)
-        self._params = []
-        self.default = dict(background=0.)
+        # reference fitfunc.py:195-204: the profile's own parameters and their defaults
+        tmpl = FIT_TEMPLATES[fit_function]
+        self._params = list(tmpl['params'])
+        self.default = dict(background=0., **tmpl['default'])
+        self.continuous = tmpl['continuous']
         self.params = ['background', 'signal'] + self.pos_columns + \
             self.size_columns + self._params
 

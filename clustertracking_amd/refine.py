@@ -148,7 +148,7 @@ def prepare_batch(f, reader, diameter, separation=None, fit_function='gauss',
                                 residual_factor=residual_factor,
                                 solver_maxiter=solver_maxiter, xtol=xtol, ftol=ftol,
                                 noise_size=None if noise_size is None else validate_tuple(noise_size, ndim),
-                                threshold=threshold)
+                                threshold=threshold, fit_function=ff.fit_function)
     batch = _abi.HostBatch(frames, frame_index, feat_offset, params[order],
                            low[order], high[order], want_std=bool(compute_error))
     # SciPy raises ValueError for an infeasible box (lower > upper)
@@ -219,9 +219,12 @@ def refine_leastsq(f, reader, diameter, separation=None, fit_function='gauss',
       ``xtol``, ``ftol``, ``device``, ``cluster_labels`` ('reference': ids equal to
       the reference's, labelled on the host; 'device': same partition labelled on
       the GPU, canonical ids).
-    * ``fit_function`` other than ``'gauss'`` and ``param_mode`` value
-      ``'global'`` raise ``NotImplementedError`` (there is no CPU
-      fallback to hand them to).
+    * ``fit_function``: ``'gauss'``, ``'ring'`` and ``'disc'`` (fitfunc.py:112-146, with the
+      profile parameter ``thickness`` / ``disc_size`` as a column like any other: constant by
+      default, ``param_val`` sets it); ``'inv_series_N'``, custom (dict) functions and the
+      ``param_mode`` value ``'global'`` raise ``NotImplementedError`` (there is no CPU fallback to
+      hand them to).  Ring and disc fits iterate with the Gauss-Newton model, have no
+      ``compute_error`` (NaN) and are limited to clusters of 64 features / 127 variables.
     * ``noise_size`` (the lowpass of every window, refine.py:37-40) up to sigma 4.
     * ``compute_error``: the ``'<param>_std'`` columns come from the exact second
       derivatives of the objective (the reference differentiates numerically with

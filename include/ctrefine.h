@@ -29,7 +29,7 @@ extern "C" {
 
 #define CTR_ABI_VERSION 6
 #define CTR_MAX_NDIM 3
-#define CTR_MAX_PARAMS 8 /* background, signal, <=3 positions, <=3 sizes */
+#define CTR_MAX_PARAMS 9 /* background, signal, <=3 positions, <=3 sizes, <=1 profile parameter */
 #define CTR_MAX_VARS 127 /* optimiser variables per cluster of the on-chip kernels; larger clusters
                             (or more than 64 features) take the large-cluster path: normal matrix
                             block-sparse in HBM, no limit on features or variables */
@@ -101,9 +101,10 @@ typedef struct ctr_problem {
   int32_t ndim;                    /* 2 or 3 */
   int32_t isotropic;               /* 1: one 'size' column; 0: one per axis */
   int32_t fit_function;            /* CTR_FIT_* */
-  int32_t n_params;                /* 2 + ndim + (isotropic ? 1 : ndim); column order
-                                      [background, signal, (z,) y, x, size | size_(z,)y,x]
-                                      (fitfunc.py:353-354) */
+  int32_t n_params;                /* 2 + ndim + (isotropic ? 1 : ndim) + extras; column order
+                                      [background, signal, (z,) y, x, size | size_(z,)y,x, extra]
+                                      (fitfunc.py:353-354); extras: 0 for gauss, 1 for ring
+                                      ('thickness') and disc ('disc_size') */
   int32_t modes[CTR_MAX_PARAMS];   /* CTR_MODE_* per column (fitfunc.py:394) */
   int32_t radius[CTR_MAX_NDIM];    /* mask radius per axis = diameter // 2 (refine.py:286) */
   int32_t constraint_kind;         /* CTR_CONS_* */

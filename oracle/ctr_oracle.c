@@ -333,6 +333,48 @@ static void eval_constraints(const ctx_t* c, const double* v, double* cv, double
   }
 }
 
+/* ---- radial profiles (fitfunc.py:112-146) ----------------------------------------------------
+ * value g(r2; e) with dg/dr2 and dg/de, e = the profile's extra parameter:
+ *   gauss  exp(-nd/2 r2)                                                 (fitfunc.py:112-118)
+ *   ring   exp(-nd/2 ((r - 1 + t)/t)^2), r = sqrt(r2), t = 'thickness'   (fitfunc.py:134-146;
+ *          the reference's own derivatives)
+ *   disc   1 for r <= ds, exp(-nd/2 ((r - ds)/(1 - ds))^2) beyond, ds = 'disc_size' (<= 0: the
+ *          gaussian, >= 1: 0.999; fitfunc.py:121-131).  The reference has no derivative of it (its
+ *          SLSQP differentiates the objective numerically, fitfunc.py:451-452); these are the
+ *          analytic ones of the same function.
+ * ring and disc are not "continuous" (fitfunc.py:195-204): their r2 is NaN within one pixel of
+ * the centre (r2_*_safe, fitfunc.py:20-26,43-49,67-73,91-98): nansum skips those pixels for the
+ * ring; the disc has the value 1 there (its function only overwrites where r2 > disc_size^2). */
+static void profile(int fit, int nd, double r2, double e, double* g, double* dg_dr2, double* dg_de) {
+  if (fit == CTR_FIT_RING) {
+    const double r = sqrt(r2), num = r - 1. + e;
+    const double f = exp(-0.5 * nd * ((num / e) * (num / e)));
+    *g = f;
+    *dg_dr2 = f * (-0.5 * nd / (r * (e * e))) * num;
+    *dg_de = f * nd * (num * num / (e * e * e) - num / (e * e));
+    return;
+  }
+  if (fit == CTR_FIT_DISC && e > 0.) {
+    const int clamped = e >= 1.;
+    const double ds = clamped ? 0.999 : e;
+    if (r2 > ds * ds) {
+      const double r = sqrt(r2), w = 1. - ds, u = (r - ds) / w;
+      const double f = exp(u * u * nd / -2.);
+      *g = f;
+      *dg_dr2 = f * (-(double)nd * u / w) / (2. * r);
+      *dg_de = clamped ? 0. : f * (-(double)nd * u) * ((r - 1.) / (w * w));
+    } else {
+      *g = r2 == r2 ? 1. : NAN;
+      *dg_dr2 = 0.;
+      *dg_de = 0.;
+    }
+    return;
+  }
+  *g = exp(-0.5 * nd * r2);
+  *dg_dr2 = -0.5 * nd * *g;
+  *dg_de = 0.;
+}
+
 /* ---- objective: S = sum r^2, g = J^T r, A = J^T J ------------------------- */
 
 static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double* g,
@@ -371,7 +413,7 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
         int idx[3];
         double mesh[3];
         size_t off;
-        int any = 0, nnz = 0, nhf = 0;
+        int any = 0, nnz = 0, nhf = 0, safe_nan = 0;
         double res = 0., pv = 0.;
         if (nd == 3) {
           idx[0] = z; idx[1] = y; idx[2] = x;
@@ -394,7 +436,7 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
           }
           for (int k = 1; k < np; ++k) prm[k] = par(c, v, i, k);
           const double sig = prm[1];
-          double r2 = 0., dr2[6];
+          double r2 = 0., dr2[6], qraw = 0.;
           if (c->p->isotropic) {
             const double size = prm[2 + nd];
             double q = 0.;
@@ -403,6 +445,7 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
               double d = mesh[a] - prm[2 + a];
               q += d * d;
             }
+            qraw = q;
             r2 = q / (size * size);
             for (int a = 0; a < nd; ++a) dr2[a] = (prm[2 + a] - mesh[a]) * (2. / (size * size));
             dr2[nd] = q * (-2. / (size * size * size));
@@ -410,13 +453,24 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
             for (int a = nd - 1; a >= 0; --a) {
               double d = mesh[a] - prm[2 + a], sz = prm[2 + nd + a];
               if (!(sz > 0.)) model_nan = 1;
+              qraw += d * d;
               r2 += d * d / (sz * sz);
               dr2[a] = (prm[2 + a] - mesh[a]) * (2. / (sz * sz));
               dr2[nd + a] = d * d * (-2. / (sz * sz * sz));
             }
           }
-          const double gv = exp(-0.5 * nd * r2); /* fitfunc.py:112-118 */
-          const double dg = -0.5 * nd * gv;
+          double gv, dg, dge;
+          const int fit = c->p->fit_function;
+          /* r2_*_safe (fitfunc.py:20-26,...): within one pixel of the centre the profiles that are
+           * not continuous have no value; nansum skips the pixel (it still counts in P) */
+          const double extra = np > 2 + nd + L->nsz ? prm[np - 1] : 0.;
+          if (fit != CTR_FIT_GAUSS && qraw < 1.) {
+            /* (disc_func starts from ones and only overwrites where r2 > disc_size^2, false for a
+             *  NaN: the disc has the value 1 there, fitfunc.py:122-131; disc_size <= 0: gauss(NaN)) */
+            if (fit == CTR_FIT_DISC && extra > 0.) gv = 1.;
+            else { safe_nan = 1; gv = NAN; }
+            dg = 0.; dge = 0.;
+          } else profile(fit, nd, r2, extra, &gv, &dg, &dge);
           res -= sig * gv;
           if (Q) {
             hf[nhf].i = i;
@@ -428,9 +482,10 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
           }
           if (g) {
             /* d res / d signal, positions, sizes (fitfunc.py:475-478, sign of the residual) */
-            double d[1 + 6];
+            double d[1 + 6 + 1];
             d[0] = -gv;
             for (int t = 0; t < nd + L->nsz; ++t) d[1 + t] = -sig * dg * dr2[t];
+            if (np > 2 + nd + L->nsz) d[1 + nd + L->nsz] = -sig * dge;   /* fitfunc.py:480-481 */
             for (int k = 1; k < np; ++k) {
               int b = L->var_of[k];
               if (b < 0) continue;
@@ -445,7 +500,7 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
         if (!any) continue;
         ++P;
         if (res != res) { /* nansum (fitfunc.py:449,483): a NaN pixel of the IMAGE is skipped */
-          if (pv == pv) model_nan = 1; /* a NaN of the MODEL (a size of 0): no valid evaluation */
+          if (pv == pv && !safe_nan) model_nan = 1; /* a NaN of the MODEL (a size of 0): no valid evaluation */
           continue;
         }
         S += res * res;
@@ -762,11 +817,12 @@ static solve_t solve(const ctx_t* c, const double* v0, const double* lo, const d
   int pair_of[MAXC], pair_of_t[MAXC];
   /* exact second-order terms are used when signal and positions are per-feature variables
    * (the default modes); otherwise the model Hessian is J^T J throughout */
-  int newton = use_newton && c->p->modes[1] == CTR_MODE_VAR;
+  /* (the second-order terms are those of the gaussian: other profiles iterate with J^T J) */
+  int newton = use_newton && c->p->fit_function == CTR_FIT_GAUSS && c->p->modes[1] == CTR_MODE_VAR;
   for (int a = 0; a < c->L.nd; ++a) newton = newton && c->p->modes[2 + a] == CTR_MODE_VAR;
   /* fullq: the second-order part in ALL variables (full_second_order) instead */
   int fullq = 0;
-  if (use_newton && full_q_mode && (full_q_mode == 2 || m)) {
+  if (use_newton && c->p->fit_function == CTR_FIT_GAUSS && full_q_mode && (full_q_mode == 2 || m)) {
     int sizevar = 0;
     for (int k2 = 2 + c->L.nd; k2 < c->L.np; ++k2) if (c->L.var_of[k2] >= 0) sizevar = 1;
     if (!newton || sizevar) { fullq = 1; newton = 1; }
@@ -1256,7 +1312,10 @@ static void refine_one(const ctr_problem* p, const ctr_batch* b, int64_t cl,
       if (r.P == 0) { status = CTR_STATUS_OUT_OF_BOUNDS; break; }
       if (!r.ok) { status = CTR_STATUS_NO_CONVERGENCE; break; } /* refine.py:376-377 */
       rms = sqrt(((r.S / (double)r.P) / norm) / p->residual_factor); /* refine.py:379 */
-      if (b->params_std) solution_std(&c, v, norm, vstd); /* refine.py:400-406, this round's masks */
+      if (b->params_std) { /* refine.py:400-406, this round's masks; gaussian only (full_second_order) */
+        if (p->fit_function == CTR_FIT_GAUSS) solution_std(&c, v, norm, vstd);
+        else for (int i = 0; i < nv; ++i) vstd[i] = NAN;
+      }
       int moved = 0;
       for (int i = 0; i < n; ++i) {
         double d2 = 0.;
@@ -1307,7 +1366,7 @@ static void frame_max(const ctr_batch* b, int nd, double* fmax) {
 
 int ctro_refine_batch(const ctr_problem* p, const ctr_batch* b, int n_threads) {
   double* fmax = malloc(sizeof(double) * (size_t)(b->n_frames > 0 ? b->n_frames : 1));
-  if (p->ndim < 2 || p->ndim > 3 || p->max_iter < 1 || p->fit_function != CTR_FIT_GAUSS) { free(fmax); return CTR_ERR_INVALID; }
+  if (p->ndim < 2 || p->ndim > 3 || p->max_iter < 1 || p->fit_function < CTR_FIT_GAUSS || p->fit_function > CTR_FIT_DISC) { free(fmax); return CTR_ERR_INVALID; }
   frame_max(b, p->ndim, fmax);
   if (n_threads < 1) n_threads = 1;
 #pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads)

@@ -102,7 +102,7 @@ def refine_leastsq_sharded(*args, **kwargs):
 def is_solver_specific(name):
     """Fixtures whose outcome depends on the minimiser itself: constrained fits that one of the
     reference's two runs (defaults = A, converged = B) fails, or that end in poor minima."""
-    return name.startswith('hard_cons_') or name.startswith('tetramer2d_')
+    return name.startswith('hard_cons_') or name.startswith('tetramer2d_') or name == 'ring_2d_a_thickness'
 
 
 # (fixture, cluster id): the reference fits it and the engine's minimiser returns NaN.  EMPTY since
@@ -122,8 +122,15 @@ KNOWN_FAIL_HERE = set()
 # both directions about equally often: 14 end higher here, 18 lower, 69 agree, 1 fails here only
 # (a 2D tetramer at the kink of constraints.py:102-114), 1 there only.  The list is strict: a
 # cluster named here that no longer ends higher fails the test (so the list cannot go stale).
+#   ring_2d_a_thickness / 0, 3, 11: rings with free sizes AND a free thickness per cluster, started
+#     12 % off in thickness: a sharp, multi-modal objective (the reference's own default run fails on
+#     cluster 0 and ends 14x higher than its converged run on cluster 4); the Gauss-Newton iteration
+#     of the ring profile ends in a neighbouring minimum for 3 of the 16 clusters, and lower than the
+#     reference for 2.  With the thickness held at its value (ring_2d_a_sizevar, the regime of the
+#     reference's own tests) every cluster agrees to 3e-8 px.
 OTHER_MINIMUM = {('hard_cons_trimer', 2), ('hard_cons_trimer_sizecluster', 6),
-                 ('hard_cons_dimer_sizevar', 11)}
+                 ('hard_cons_dimer_sizevar', 11),
+                 ('ring_2d_a_thickness', 0), ('ring_2d_a_thickness', 3), ('ring_2d_a_thickness', 11)}
 
 
 def check_solver_specific(name, res, A, B, pos_columns):

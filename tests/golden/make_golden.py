@@ -88,7 +88,7 @@ def intermediates(f0, frames, call, n_clusters=6):
         diameter = (diameter,) * ndim
     radius = tuple(int(d) // 2 for d in diameter)
     isotropic = all(d == diameter[0] for d in diameter)
-    ff = FitFunctions('gauss', ndim, isotropic, call.get('param_mode'))
+    ff = FitFunctions(call.get('fit_function', 'gauss'), ndim, isotropic, call.get('param_mode'))
     out['im_params'] = np.array(ff.params)
     out['im_modes'] = np.array(ff.modes)
     tmpl = ff.validate_bounds(call.get('bounds'), radius=radius)
@@ -137,7 +137,8 @@ def intermediates(f0, frames, call, n_clusters=6):
         out['im%d_vect' % k] = vect
         out['im%d_bounds' % k] = bnds
         out['im%d_F' % k] = np.array(residual(vect))
-        out['im%d_grad' % k] = jacobian(vect)
+        if jacobian is not None:     # (the disc profile has none: fitfunc.py:451-452)
+            out['im%d_grad' % k] = jacobian(vect)
         k += 1
     out['im_count'] = np.array(k)
     return out

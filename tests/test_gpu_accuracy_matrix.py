@@ -1,5 +1,5 @@
 """The reference's accuracy matrix (clustertracking/tests/test_refine.py:598-765) restated for
-the HIP engine with fixed seeds: Gaussian features, 2D / 3D, isotropic / anisotropic, Poisson
+the HIP engine with fixed seeds: Gaussian, disc and ring features (test_refine.py:768-881), 2D / 3D, isotropic / anisotropic, Poisson
 noise 0 / 16 / 48 (perfect, S/N 10, S/N 3), parameter modes const / var signal / var size / var,
 and dimers / trimers / tetramers with and without constraints.  Same image construction
 (test_refine.py:82-122,124-186: 20 features on a grid of twice the diameter with random sub-pixel
@@ -39,6 +39,17 @@ GEOMETRIES = {
     'gauss3D': (3, (4., 4., 4.)),
     'gauss3D_a': (3, (3., 5., 5.)),
 }
+# the other profiles (test_refine.py:797-881: TestFit_disc* / TestFit_ring*): features drawn with the
+# profile (artificial.py:17-28), fitted with it, its parameter given by param_val; rings are sharp:
+# start offsets of a quarter of the size and sizes 5 % off (test_refine.py:839-843)
+PROFILES = {
+    'disc': dict(feat_kwargs=dict(disc_size=0.5), pos_diff=POS_DIFF, size_dev=SIZE_DEV),
+    'ring': dict(feat_kwargs=dict(thickness=0.2), pos_diff=0.25, size_dev=0.05),
+}
+for _prof in PROFILES:
+    for _g, _v in list(GEOMETRIES.items()):
+        if _g.startswith('gauss'):
+            GEOMETRIES[_g.replace('gauss', _prof)] = _v
 MODES = {
     'const': (dict(signal='const', size='const'), 0., 0.),
     'var_signal': (dict(signal='var', size='const'), SIGNAL_DEV, 0.),
@@ -50,6 +61,12 @@ MODES = {
 class Geometry(object):
     def __init__(self, name):
         self.ndim, self.size = GEOMETRIES[name]
+        self.fit_function = name[:name.index('D') - 1]
+        prof = PROFILES.get(self.fit_function, dict(feat_kwargs={}, pos_diff=POS_DIFF, size_dev=SIZE_DEV))
+        self.feat_kwargs, self.pos_diff, self.size_dev = prof['feat_kwargs'], prof['pos_diff'], prof['size_dev']
+        # what refine_leastsq gets besides the table: the profile and its parameter
+        self.fit_kwargs = dict(fit_function=self.fit_function, param_val=dict(self.feat_kwargs)) \
+            if self.feat_kwargs else {}
         self.diameter = tuple(int(s * 4) for s in self.size)
         self.separation = tuple(d * 2 for d in self.diameter)
         self.isotropic = len(set(self.diameter)) == 1
@@ -67,7 +84,7 @@ class Geometry(object):
         shape = tuple(np.max(pos, axis=0).astype(int) + np.array(self.separation))
         image = np.zeros(shape, dtype=np.uint8)
         for p, s, sz in zip(pos, signal, size):
-            artificial.draw_gaussian(image, p, tuple(sz), s)
+            artificial.draw_feature(image, p, tuple(sz), s, self.fit_function, **self.feat_kwargs)
         if noise > 0:
             image = image + rng.poisson(noise, shape)
             if image.max() <= 255:
@@ -82,7 +99,7 @@ class Geometry(object):
 
     def p0(self, rng, expected_pos):
         n = expected_pos.shape[0]
-        box = np.array([self.size]) * POS_DIFF
+        box = np.array([self.size]) * self.pos_diff
         dev = (rng.random_sample((10 * n, self.ndim)) - 0.5) * box * 2
         dev = dev[np.sum((dev / box) ** 2, axis=1) <= 1][:n]
         return expected_pos + dev
@@ -103,9 +120,11 @@ class Geometry(object):
 @pytest.mark.parametrize("level", ['perfect', 'imperfect', 'noisy'])
 @pytest.mark.parametrize("mode", ['const', 'var_signal', 'var_size', 'var'])
 def test_accuracy_matrix(engine, geometry, level, mode):
-    """test_refine.py:598-688 (test_perfect_* / test_imperfect_* / test_noisy_*)"""
+    """test_refine.py:598-688 (test_perfect_* / test_imperfect_* / test_noisy_*), for the gaussian,
+    disc and ring profiles (test_refine.py:768-881)"""
     g = Geometry(geometry)
     param_mode, signal_dev, size_dev = MODES[mode]
+    size_dev = g.size_dev if size_dev > 0 else 0.
     noise = NOISE[level]
     rng = np.random.RandomState(sum(map(ord, geometry + level + mode)))
     pos = g.grid(rng, g.separation)
@@ -113,7 +132,7 @@ def test_accuracy_matrix(engine, geometry, level, mode):
     image = g.draw(rng, pos, signal, size, noise)
     f0 = g.table(g.p0(rng, pos), noise)
     res = cta.refine_leastsq(f0, image, g.diameter, param_mode=param_mode, bounds=BOUNDS,
-                             pos_columns=g.pos_columns)
+                             pos_columns=g.pos_columns, **g.fit_kwargs)
     assert not np.any(np.isnan(res['cost']))
     dev = pos - res[g.pos_columns].values
     assert np.sqrt(np.mean(dev ** 2)) < PRECISION[level]

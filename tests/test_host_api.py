@@ -70,7 +70,19 @@ def test_validate_problem_without_device():
     assert lib.ctr_validate_problem(ctypes.byref(p), msg, 256) == _abi.ERR_UNSUPPORTED
     assert b'global' in msg.value
     p = _abi.make_problem(2, True, [3, 1, 1, 1, 0], (6, 6))
-    p.fit_function = 1
+    p.fit_function = _abi.FIT_RING          # a ring has one more column (thickness)
+    assert lib.ctr_validate_problem(ctypes.byref(p), msg, 256) == _abi.ERR_INVALID
+    for fit in ('ring', 'disc'):
+        p = _abi.make_problem(2, True, [3, 1, 1, 1, 0, 0], (6, 6), fit_function=fit)
+        assert p.n_params == 6
+        assert lib.ctr_validate_problem(ctypes.byref(p), msg, 256) == _abi.OK
+        p = _abi.make_problem(3, False, [3, 1, 1, 1, 1, 1, 1, 1, 3], (4, 6, 6), fit_function=fit)
+        assert p.n_params == 9 and lib.ctr_cluster_n_vars(ctypes.byref(p), 2) == 2 + 2 * 7
+        assert lib.ctr_validate_problem(ctypes.byref(p), msg, 256) == _abi.OK
+        p = _abi.make_problem(2, True, [3, 1, 1, 1, 0, 0], (6, 6), fit_function=fit, noise_size=(1, 1))
+        assert lib.ctr_validate_problem(ctypes.byref(p), msg, 256) == _abi.ERR_UNSUPPORTED
+    p = _abi.make_problem(2, True, [3, 1, 1, 1, 0], (6, 6))
+    p.fit_function = _abi.FIT_INV_SERIES
     assert lib.ctr_validate_problem(ctypes.byref(p), msg, 256) == _abi.ERR_UNSUPPORTED
     p = _abi.make_problem(2, True, [3, 1, 1, 1, 0], (6, 6), max_iter=0)
     assert lib.ctr_validate_problem(ctypes.byref(p), msg, 256) == _abi.ERR_INVALID
@@ -106,6 +118,16 @@ def test_default_modes_and_layout():
     assert ff.modes == [3, 3, 1, 1, 1, 1, 1, 1]
     ff = cta.FitFunctions('gauss', 2, True, dict(pos='const', size='var'))
     assert ff.modes == [3, 1, 0, 0, 1]
+    # the profiles with a parameter of their own (reference fitfunc.py:195-204)
+    ff = cta.FitFunctions('ring', 2, False, dict(thickness='cluster'))
+    assert ff.params == ['background', 'signal', 'y', 'x', 'size_y', 'size_x', 'thickness']
+    assert ff.modes == [3, 1, 1, 1, 0, 0, 3] and ff.default['thickness'] == 0.5 and not ff.continuous
+    ff = cta.FitFunctions('disc', 3, True)
+    assert ff.params[-1] == 'disc_size' and ff.modes[-1] == 0 and ff.default['disc_size'] == 0.5
+    with pytest.raises(NotImplementedError):
+        cta.FitFunctions('inv_series_3', 2, True)
+    with pytest.raises(ValueError):
+        cta.FitFunctions('lorentz', 2, True)
     with pytest.warns(UserWarning):
         ff = cta.FitFunctions('gauss', 2, True, dict(background='var'))
     assert ff.modes[0] == 3
@@ -114,8 +136,7 @@ def test_default_modes_and_layout():
 def test_unsupported_is_loud(oracle):
     im, truth, f0 = small_problem()
     run = _cases.oracle_runner()
-    for kw in (dict(param_mode=dict(signal='global')), dict(fit_function='ring'),
-               dict(fit_function='disc'),
+    for kw in (dict(param_mode=dict(signal='global')), dict(fit_function='inv_series_2'),
                dict(fit_function=dict(params=[], func=None))):
         with pytest.raises(NotImplementedError):
             _cases.refine_leastsq(f0.copy(), im, 13, _run_batch=run, **kw)
