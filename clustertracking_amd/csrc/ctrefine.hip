@@ -21,6 +21,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <mutex>
@@ -71,6 +72,7 @@ struct ctr_plan {
   // The workspace belongs to the plan: calls that use one plan must not overlap in time.
   double* d_ws = nullptr;
   long long* d_ws_off = nullptr;   // [n_clusters] offset in doubles (0 for the other clusters)
+  mutable int large_epoch = 0;     // launches of the large kernel on this plan (tags its leader / helper words)
   int64_t bin_begin[NBINS + 1] = {0};
   int64_t bin_count[NBINS] = {0};
   // lowpass of the window (ctr_problem.noise_size): taps per axis on the device (kargs.h: lp_w)
@@ -455,7 +457,9 @@ int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
         ctr_plan_destroy(plan);
         return fail(h, CTR_ERR_NOMEM, "cannot allocate the workspace of the large clusters on the device");
       }
-      if (hipMemcpy(plan->d_ws_off, ws_off.data(), sizeof(long long) * (size_t)n_clusters, hipMemcpyHostToDevice) != hipSuccess) {
+      // (the leader / helper words of every cluster start at zero: no epoch matches)
+      if (hipMemset(plan->d_ws, 0, sizeof(double) * (size_t)ws_total) != hipSuccess ||
+          hipMemcpy(plan->d_ws_off, ws_off.data(), sizeof(long long) * (size_t)n_clusters, hipMemcpyHostToDevice) != hipSuccess) {
         ctr_plan_destroy(plan);
         return fail(h, CTR_ERR_DEVICE, "cannot upload the plan");
       }
@@ -606,7 +610,8 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     HIP_TRY(h, hipLaunchKernel(ki.fn, dim3((unsigned)cnt), dim3((unsigned)ki.threads), kargs, ki.smem, pick_stream(false)));
   }
   if (plan->bin_count[BIN_LARGE] > 0) {
-    // one 1024-thread workgroup per cluster, all of a CU's LDS: first in the queue
+    // a leader workgroup of 512 threads per cluster + helpers for its pixel passes
+    // (large_kernel.h): as many as fill the machine, none when the clusters alone do
     const int64_t cnt = plan->bin_count[BIN_LARGE];
     const int lpi = plan->lowpass ? 1 : 0;
     const KernelInfo& ki = h->large[di][ii][lpi];
@@ -614,15 +619,22 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
       HIP_TRY(h, hipFuncSetAttribute(ki.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ki.smem));
       h->large_attr[di][ii][lpi] = true;
     }
+    int64_t per_cluster = 512 / cnt;               // workgroups per cluster, leader included
+    per_cluster = per_cluster < 1 ? 1 : (per_cluster > 8 ? 8 : per_cluster);
+    if (const char* e = std::getenv("CTR_LARGE_WORKGROUPS")) {   // (measurements)
+      const long v = std::strtol(e, nullptr, 10);
+      if (v >= 1 && v <= 16) per_cluster = v;
+    }
     k.order = ord + plan->bin_begin[BIN_LARGE];
     k.n_bin = (int32_t)cnt;
     double* wsp = plan->d_ws;
     const long long* wso = plan->d_ws_off;
-    void* kargs[] = {(void*)&k, (void*)&wsp, (void*)&wso};
+    int epoch = ++plan->large_epoch;
+    void* kargs[] = {(void*)&k, (void*)&wsp, (void*)&wso, (void*)&epoch};
     slow_tier = true;
     hipStream_t sl = pick_stream(false);
     slow_tier = false;
-    HIP_TRY(h, hipLaunchKernel(ki.fn, dim3((unsigned)cnt), dim3((unsigned)ki.threads), kargs, ki.smem, sl));
+    HIP_TRY(h, hipLaunchKernel(ki.fn, dim3((unsigned)(cnt * per_cluster)), dim3((unsigned)ki.threads), kargs, ki.smem, sl));
   }
   if (plan->bin_count[BIN_TOO_LARGE] > 0) {
     const int64_t cnt = plan->bin_count[BIN_TOO_LARGE];

@@ -58,7 +58,7 @@ constexpr int LARGE_MAXNB = 48;   // neighbours (features with overlapping mask 
 
 struct LargeWs {
   long long nvp, nvp_i;   // variables / features rounded up to a multiple of 8
-  long long o_vec, o_cur, o_mco, o_fpar, o_pre, o_uq, o_tile, o_off, o_offc, o_int, total;
+  long long o_vec, o_cur, o_mco, o_fpar, o_pre, o_uq, o_tile, o_off, o_offc, o_int, o_sync, total;
 };
 
 // n features, npf per-feature and ns shared variables
@@ -78,11 +78,14 @@ __host__ __device__ inline LargeWs large_ws(int n, int npf, int ns) {
   W.o_off = o;  o += 2 * nn * LARGE_MAXNB * 64;  // accepted / trial neighbour blocks
   W.o_offc = o; o += nn * LARGE_MAXNB * npf * npf;  // accepted blocks, packed (the CG's copy)
   W.o_int = o;  o += (W.nvp_i + 2 * nn * LARGE_MAXNB + 1) / 2 + 8;   // nbcnt, nbidx, rev (int32)
+  o = (o + 15) & ~15LL;
+  W.o_sync = o; o += 64;                         // leader / helper words (large_kernel.h: LSY_*), zero at plan creation
   W.total = (o + 31) & ~31LL;
   return W;
 }
 
-// refine_large_kernel<ND, ISO>(KArgs, double* ws, const long long* ws_off_of_cluster)
+// refine_large_kernel<ND, ISO>(KArgs, double* ws, const long long* ws_off_of_cluster, int epoch):
+// grid = n_bin leaders + n_bin * (G - 1) helpers (large_kernel.h)
 // refine_block_kernel<ND, ISO, NT, W, CONS>: nt = 1..8; throughput != 0: the fewest wavefronts;
 // cons != 0: the instantiation for clusters with equality constraints (nt = 1, 2 only)
 KernelInfo ctr_block_kernel_2d(int iso, int nt, int throughput, int cons);

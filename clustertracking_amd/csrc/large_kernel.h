@@ -1,5 +1,6 @@
 // large_kernel.h -- refine_large_kernel: clusters beyond the block kernel (> 64 features or
-// > 127 variables), one 1024-thread workgroup per cluster, the normal matrix block-sparse in HBM/L2.
+// > 127 variables): a LEADER workgroup of 512 threads per cluster runs the solver, up to 7 HELPER
+// workgroups share its pixel passes; the normal matrix is block sparse in HBM/L2.
 // Part of the MI355X cluster-refinement engine; included by tu_large.hip inside its anonymous
 // namespace (device code only, gfx950).
 //
@@ -66,20 +67,59 @@ __device__ __forceinline__ bool wg_any(bool x, double* red, int lane, int wave) 
   return __syncthreads_or(x ? 1 : 0) != 0;
 }
 
-// diagnostic counters (tests/tools/run_cfg3.py via ctr_debug_large_counters): [0] linear
-// solves, [1] conjugate-gradient iterations, [2] pixel passes
-__device__ unsigned long long g_large_dbg[8];   // [4] ticks (100 MHz) in pixel passes, [5] in solves
+// diagnostic counters of the CTR_STAMPS build only (tests/tools/run_cfg3.py via
+// ctr_debug_large_counters): [0] linear solves, [1] conjugate-gradient iterations, [2] pixel
+// passes, [3] ticks (100 MHz) in matrix-vector products, [4] in pixel passes, [5] in solves,
+// [6] / [7] wave 0 of the leader in feature tiles / pair blocks
+#ifdef CTR_STAMPS
+__device__ unsigned long long g_large_dbg[8];
+#define LDBG_ADD(slot, val) atomicAdd(&g_large_dbg[slot], (unsigned long long)(val))
+#define LDBG_NOW() __builtin_amdgcn_s_memrealtime()
+#else
+#define LDBG_ADD(slot, val) do {} while (0)
+#define LDBG_NOW() 0ull
+#endif
+
+// ---- leader / helpers ---------------------------------------------------------------------------
+// The pixel pass is parallel over the features (one wavefront per feature); the solver is not.
+// Grid: blocks [0, n_bin) are the leaders (block b: cluster order[b]), blocks beyond are helpers
+// (block n_bin + h: cluster order[h % n_bin]).  The leader posts a pass as a JOB in the cluster's
+// workspace; every wavefront of the leader and of whichever helpers are resident then claims
+// features from one counter until none is left.  The leader waits only for features that WERE
+// claimed -- by a wavefront that is running -- so a helper that never becomes resident costs
+// nothing and nothing can deadlock; helpers leave when the leader posts EXIT (tagged with the
+// launch's epoch: a stale word of an earlier launch is never mistaken for it).  Visibility between
+// workgroups: agent-scope release before a flag / counter, agent-scope acquire behind it
+// (MI355X_MICROARCH.md, inter-workgroup visibility); every spin is bounded.
+constexpr int LSY_JOB = 0, LSY_EXIT = 1, LSY_CLAIM = 16, LSY_DONE = 17, LSY_P = 18, LSY_DESC = 32;
+constexpr unsigned long long LARGE_SPIN_TICKS = 3000000000ull;   // 30 s at 100 MHz
+
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void release_agent() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void acquire_agent() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
 // LP: with the lowpass of the window (ctr_problem.noise_size; device_common.h:lowpass_pixel)
 template <int ND, bool ISO, bool LP = false>
 __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double* __restrict__ ws_base,
-                                                          const long long* __restrict__ ws_off) {
+                                                          const long long* __restrict__ ws_off, const int epoch) {
   constexpr int NP = 2 + ND + (ISO ? 1 : ND);
   constexpr int NSZ = ISO ? 1 : ND;
   constexpr int MAXPF = 7;   // per-feature variables: signal + ND positions + NSZ sizes
   extern __shared__ double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cl = k.order[blockIdx.x];
+  const bool helper = (int)blockIdx.x >= k.n_bin;
+  const int cl = k.order[helper ? ((int)blockIdx.x - k.n_bin) % k.n_bin : (int)blockIdx.x];
   const int f0 = k.feat_offset[cl], n = k.feat_offset[cl + 1] - f0;
   const double* params = k.params + (size_t)f0 * NP;
   double* pout = k.params_out + (size_t)f0 * NP;
@@ -108,6 +148,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
   int* nbcnt = (int*)(ws + W.o_int);
   int* nbidx = nbcnt + W.nvp_i;
   int* rev = nbidx + (size_t)n * LARGE_MAXNB;
+  unsigned long long* sy = (unsigned long long*)(ws + W.o_sync);   // leader / helper words (LSY_*)
 
   // the exact second-order terms need signal and positions as per-feature variables
   bool newton_on = L.slot[1] >= 0 && L.per_feat[1];
@@ -147,99 +188,33 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
     return vv[b];
   };
 
-  // ---- set-up ------------------------------------------------------------------------------
-  bool finite = true;
-  for (int e = tid; e < n * NP; e += LT) {
-    const double x = params[e];
-    pout[e] = x;  // failures keep their input (refine.py:408-418)
-    cur[(e / NP) * CTR_MAX_PARAMS + (e % NP)] = x;
-    if (!isfinite(x)) finite = false;
-  }
-  for (int e = tid; e < LW * WAVE * LRS; e += LT) smem[SmemL::o_rows + e] = 0.;
-  for (int e = tid; e < n * 3; e += LT) {
-    const int i = e / 3, a = e % 3;
-    mco[e] = a < ND ? params[i * NP + 2 + a] : 0.;
-  }
-  if (k.params_std != nullptr)   // (no covariance output for clusters of this size: documented)
-    for (int e = tid; e < n * NP; e += LT) k.params_std[(size_t)f0 * NP + e] = NAN;
-  {
-    const double* low = k.low + (size_t)f0 * NP;
-    const double* high = k.high + (size_t)f0 * NP;
-#pragma unroll
-    for (int kk = 0; kk < NP; ++kk) {
-      if (L.slot[kk] < 0) continue;
-      if (L.per_feat[kk]) {
-        for (int i = tid; i < n; i += LT) {
-          const int b = L.vidx(kk, i);
-          v0[b] = params[i * NP + kk];
-          lo[b] = low[i * NP + kk];
-          hi[b] = high[i * NP + kk];
-        }
-      } else {
-        // shared: mean start (refine.py:361), loosest bound (fitfunc.py:554-557)
-        double s = 0., l = INFINITY, h = -INFINITY;
-        for (int i = tid; i < n; i += LT) {
-          s += params[i * NP + kk];
-          l = fmin(l, low[i * NP + kk]);
-          h = fmax(h, high[i * NP + kk]);
-        }
-        double sv[1] = {s};
-        wg_sum(sv, 1, red, lane, wave);
-        l = -wg_max(-l, red, lane, wave);
-        h = wg_max(h, red, lane, wave);
-        if (tid == 0) {
-          const int b = L.vidx(kk, 0);
-          v0[b] = sv[0] / n;
-          lo[b] = l;
-          hi[b] = h;
-        }
-      }
-    }
-  }
-  const bool nonfinite = wg_any(!finite, red, lane, wave);
-
-  int status = nonfinite ? CTR_STATUS_NONFINITE : (n <= 0 ? CTR_STATUS_OUT_OF_BOUNDS : CTR_STATUS_OK);
-  int round = 0, it = 0, iters = 0, Pround = 0;
-  double mu = 1e-3, nu = 2., S = 0., pred = 0., rms = NAN, gain = INFINITY;
-  bool last_acc = true, bad_size = false;
-  double prev_step = INFINITY, trial_step = 0.;
-  const double fm = k.fmax[k.frame_index[cl]];
-  const double norm = fm * fm / k.prob.residual_factor;  // refine.py:354
-  const double ms2 = k.prob.max_shift * k.prob.max_shift;
   int origin[ND], wshape[ND];
 #pragma unroll
   for (int a = 0; a < ND; ++a) { origin[a] = 0; wshape[a] = 1; }
+  unsigned job_seq = 0;     // pixel passes posted in this launch (leader) / last one served (helper)
 
-  // derived constants of every feature at vv: [0] signal [1..3] centre [4..6] 1/size^2
-  // [7..9] 2/size^2 [10..12] -2/size^3
-  auto fill_fpar = [&](const double* vv, bool sizes) {
-    bool bad = false;
-    for (int i = tid; i < n; i += LT) {
-      double* f = fpar + (size_t)i * FP;
-      f[0] = par(vv, i, 1);
-#pragma unroll
-      for (int a = 0; a < ND; ++a) {
-        f[1 + a] = par(vv, i, 2 + a);
-        if (sizes) {
-          const double sz = par(vv, i, ISO ? 2 + ND : 2 + ND + a);
-          const double s2 = sz * sz;
-          bad = bad || !(sz > 0.);
-          f[4 + a] = 1. / s2;
-          f[7 + a] = 2. / s2;
-          f[10 + a] = -2. / (s2 * sz);
+  // The features of one pass over the masks at the point whose derived constants are in fpar:
+  // tiles and neighbour blocks -> (tile, off).  Every wavefront that takes part (the leader's and
+  // the resident helpers') claims one feature at a time; when none is left the wavefront publishes
+  // its share: the owned-pixel count and the number of features it completed.
+  auto pass_features = [&](double* tile, double* off, double bgv, unsigned seq) {
+    int Pown = 0, taken = 0;
+    const bool bg_var = L.slot[0] >= 0;
+    while (true) {
+      // claim the next feature of THIS pass (the counter carries the pass number: a wavefront
+      // that is late for a pass that has ended can never take a feature of the next one)
+      int i = n;
+      if (lane == 0) {
+        unsigned long long cur_c = ld_agent(&sy[LSY_CLAIM]);
+        while ((unsigned)(cur_c >> 32) == seq && (int)(cur_c & 0xffffffffull) < n) {
+          const unsigned long long seen = atomicCAS(&sy[LSY_CLAIM], cur_c, cur_c + 1ull);
+          if (seen == cur_c) { i = (int)(cur_c & 0xffffffffull); break; }
+          cur_c = seen;
         }
       }
-    }
-    if (sizes) bad_size = wg_any(bad, red, lane, wave);
-    else __syncthreads();
-  };
-
-  // One pass over the masks at the point whose derived constants are in fpar: tiles and
-  // neighbour blocks -> (tile, off); returns P (union pixels) -- all threads.  bgv: background.
-  auto evaluate = [&](double* tile, double* off, double bgv, int& Pout) {
-    int Pown = 0;
-    const bool bg_var = L.slot[0] >= 0;
-    for (int i = wave; i < n; i += LW) {
+      i = __builtin_amdgcn_readfirstlane(i);
+      if (i >= n) break;
+      ++taken;
       // box of mask i inside the window (window indices)
       int blo[ND], bsz[ND];
       double rel_i[ND];
@@ -276,7 +251,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
 #pragma unroll
         for (int q2 = 0; q2 < 13; ++q2) nf[q2] = fpar[(size_t)nj * FP + q2];
       }
-      const unsigned long long tf0 = __builtin_amdgcn_s_memrealtime();
+      const unsigned long long tf0 = LDBG_NOW();
       v4d acc = v4d{0., 0., 0., 0.};
       constexpr int NUF = ND * (ND + 1) / 2;
       double uacc[NUF];
@@ -453,7 +428,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
           if (lane == 0) uq[(size_t)i * 16 + LQT + t] = s;   // raw sums of the TRIAL point (tabulated on accept)
         }
       }
-      const unsigned long long tf1 = __builtin_amdgcn_s_memrealtime();
+      const unsigned long long tf1 = LDBG_NOW();
       // ---- neighbour blocks: d_i d_j^T over mask i & mask j, for the neighbours j > i -------
       for (int s2 = 0; s2 < cnt; ++s2) {
         const int j = __builtin_amdgcn_readlane(nj, s2);
@@ -559,11 +534,173 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
           }
         }
       }
-      if (tid == 0) {
-        atomicAdd(&g_large_dbg[6], tf1 - tf0);
-        atomicAdd(&g_large_dbg[7], __builtin_amdgcn_s_memrealtime() - tf1);
+      if (tid == 0 && !helper) { LDBG_ADD(6, tf1 - tf0); LDBG_ADD(7, LDBG_NOW() - tf1); }
+      (void)tf0; (void)tf1;
+    }
+    if (taken > 0) {
+      const double pw = wave_sum((double)Pown);
+      release_agent();     // this wavefront's tiles and blocks are visible before its count is
+      if (lane == 0) {
+        atomicAdd(&sy[LSY_P], (unsigned long long)pw);
+        atomicAdd(&sy[LSY_DONE], (unsigned long long)taken);
       }
     }
+  };
+
+  if (helper) {
+    // ---- a helper: serve the leader's passes until it posts EXIT -----------------------------
+    for (int e = tid; e < LW * WAVE * LRS; e += LT) smem[SmemL::o_rows + e] = 0.;
+    int* hctl = (int*)(smem + SmemL::o_tot);   // [0] 1 = a pass to serve, 2 = leave
+    while (true) {
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        int what = 2;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < LARGE_SPIN_TICKS) {
+          if (ld_agent(&sy[LSY_EXIT]) == (unsigned long long)(unsigned)epoch) break;
+          const unsigned long long w = ld_agent(&sy[LSY_JOB]);
+          if ((unsigned)(w >> 32) == (unsigned)epoch && (unsigned)(w & 0xffffffffull) > job_seq) {
+            hctl[1] = (int)(w & 0xffffffffull);
+            what = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(32);
+        }
+        if (what == 1) acquire_agent();
+        hctl[0] = what;
+      }
+      __syncthreads();
+      if (hctl[0] != 1) return;
+      job_seq = (unsigned)hctl[1];
+      // the pass: which buffers, the background, the window of the round
+      const double* desc = (const double*)(sy + LSY_DESC);
+      const bool to_b = desc[0] != 0.;
+      const double bgv = desc[1];
+#pragma unroll
+      for (int a = 0; a < ND; ++a) { origin[a] = (int)desc[2 + a]; wshape[a] = (int)desc[5 + a]; }
+      pass_features(to_b ? tileB : tileA, to_b ? offB : offA, bgv, job_seq);
+    }
+  }
+  // ---- set-up ------------------------------------------------------------------------------
+  bool finite = true;
+  for (int e = tid; e < n * NP; e += LT) {
+    const double x = params[e];
+    pout[e] = x;  // failures keep their input (refine.py:408-418)
+    cur[(e / NP) * CTR_MAX_PARAMS + (e % NP)] = x;
+    if (!isfinite(x)) finite = false;
+  }
+  for (int e = tid; e < LW * WAVE * LRS; e += LT) smem[SmemL::o_rows + e] = 0.;
+  for (int e = tid; e < n * 3; e += LT) {
+    const int i = e / 3, a = e % 3;
+    mco[e] = a < ND ? params[i * NP + 2 + a] : 0.;
+  }
+  if (k.params_std != nullptr)   // (no covariance output for clusters of this size: documented)
+    for (int e = tid; e < n * NP; e += LT) k.params_std[(size_t)f0 * NP + e] = NAN;
+  {
+    const double* low = k.low + (size_t)f0 * NP;
+    const double* high = k.high + (size_t)f0 * NP;
+#pragma unroll
+    for (int kk = 0; kk < NP; ++kk) {
+      if (L.slot[kk] < 0) continue;
+      if (L.per_feat[kk]) {
+        for (int i = tid; i < n; i += LT) {
+          const int b = L.vidx(kk, i);
+          v0[b] = params[i * NP + kk];
+          lo[b] = low[i * NP + kk];
+          hi[b] = high[i * NP + kk];
+        }
+      } else {
+        // shared: mean start (refine.py:361), loosest bound (fitfunc.py:554-557)
+        double s = 0., l = INFINITY, h = -INFINITY;
+        for (int i = tid; i < n; i += LT) {
+          s += params[i * NP + kk];
+          l = fmin(l, low[i * NP + kk]);
+          h = fmax(h, high[i * NP + kk]);
+        }
+        double sv[1] = {s};
+        wg_sum(sv, 1, red, lane, wave);
+        l = -wg_max(-l, red, lane, wave);
+        h = wg_max(h, red, lane, wave);
+        if (tid == 0) {
+          const int b = L.vidx(kk, 0);
+          v0[b] = sv[0] / n;
+          lo[b] = l;
+          hi[b] = h;
+        }
+      }
+    }
+  }
+  const bool nonfinite = wg_any(!finite, red, lane, wave);
+
+  int status = nonfinite ? CTR_STATUS_NONFINITE : (n <= 0 ? CTR_STATUS_OUT_OF_BOUNDS : CTR_STATUS_OK);
+  int round = 0, it = 0, iters = 0, Pround = 0;
+  double mu = 1e-3, nu = 2., S = 0., pred = 0., rms = NAN, gain = INFINITY;
+  bool last_acc = true, bad_size = false;
+  double prev_step = INFINITY, trial_step = 0.;
+  const double fm = k.fmax[k.frame_index[cl]];
+  const double norm = fm * fm / k.prob.residual_factor;  // refine.py:354
+  const double ms2 = k.prob.max_shift * k.prob.max_shift;
+  // derived constants of every feature at vv: [0] signal [1..3] centre [4..6] 1/size^2
+  // [7..9] 2/size^2 [10..12] -2/size^3
+  auto fill_fpar = [&](const double* vv, bool sizes) {
+    bool bad = false;
+    for (int i = tid; i < n; i += LT) {
+      double* f = fpar + (size_t)i * FP;
+      f[0] = par(vv, i, 1);
+#pragma unroll
+      for (int a = 0; a < ND; ++a) {
+        f[1 + a] = par(vv, i, 2 + a);
+        if (sizes) {
+          const double sz = par(vv, i, ISO ? 2 + ND : 2 + ND + a);
+          const double s2 = sz * sz;
+          bad = bad || !(sz > 0.);
+          f[4 + a] = 1. / s2;
+          f[7 + a] = 2. / s2;
+          f[10 + a] = -2. / (s2 * sz);
+        }
+      }
+    }
+    if (sizes) bad_size = wg_any(bad, red, lane, wave);
+    else __syncthreads();
+  };
+
+  // One pass (leader, all threads): post it, take part, wait for the features the helpers
+  // claimed, then the sums over the features; returns P (union pixels).  bgv: background.
+  bool sync_lost = false;
+  auto evaluate = [&](double* tile, double* off, double bgv, int& Pout) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();           // everything the pass reads (fpar, the neighbour lists) is written
+    ++job_seq;
+    if (tid == 0) {
+      st_agent(&sy[LSY_CLAIM], (unsigned long long)job_seq << 32);
+      st_agent(&sy[LSY_DONE], 0ull);
+      st_agent(&sy[LSY_P], 0ull);
+      double* desc = (double*)(sy + LSY_DESC);
+      desc[0] = tile == tileB ? 1. : 0.;
+      desc[1] = bgv;
+#pragma unroll
+      for (int a = 0; a < ND; ++a) { desc[2 + a] = (double)origin[a]; desc[5 + a] = (double)wshape[a]; }
+      release_agent();
+      st_agent(&sy[LSY_JOB], ((unsigned long long)(unsigned)epoch << 32) | job_seq);
+    }
+    __syncthreads();
+    pass_features(tile, off, bgv, job_seq);
+    __syncthreads();
+    if (tid == 0) {
+      // features claimed by helpers are being computed by running wavefronts: this ends
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      bool got = false;
+      while (__builtin_amdgcn_s_memrealtime() - t0 < LARGE_SPIN_TICKS) {
+        if (ld_agent(&sy[LSY_DONE]) >= (unsigned long long)n) { got = true; break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      acquire_agent();
+      red[0] = got ? 1. : 0.;
+      red[1] = (double)ld_agent(&sy[LSY_P]);
+    }
+    __syncthreads();
+    if (red[0] == 0.) sync_lost = true;
+    const double Ptot = red[1];
     // sums over the features of every tile entry: the "_o" entries are the cluster totals
     __syncthreads();
     if (tid < 256) {
@@ -571,14 +708,13 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       for (int i = 0; i < n; ++i) s += tile[(size_t)i * 256 + tid];
       tot[tid] = s;
     }
-    double pv[1] = {(double)Pown};
-    wg_sum(pv, 1, red, lane, wave);   // (also orders tot[] for everybody)
-    Pout = (int)pv[0];
+    __syncthreads();   // (orders tot[] for everybody)
+    Pout = (int)Ptot;
   };
 
   // y = (B + mu diag(Dm)) x, rows of fixed variables zeroed when mk != nullptr (x is expected to
   // be zero there already); B = J^T J of (tile, off) plus, with use_q, the second-order entries
-  // uq.  One matrix row per thread at a time (n NPF rows over 1024 threads).  Returns x^T y.
+  // uq.  One matrix row per thread at a time (n NPF rows over the 512 threads).  Returns x^T y.
   auto matvec = [&](const double* x, double* y, const double* tile, const double* off, double muv,
                     bool use_q, const double* mk) -> double {
     __syncthreads();
@@ -769,11 +905,13 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       bool accept = false;
       if (need_eval) {
         int P = 0;
-        const unsigned long long te0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long te0 = LDBG_NOW();
         evaluate(tileT, offT, par(vt, 0, 0), P);
-        if (tid == 0) { atomicAdd(&g_large_dbg[2], 1ull); atomicAdd(&g_large_dbg[4], __builtin_amdgcn_s_memrealtime() - te0); }
+        if (tid == 0) { LDBG_ADD(2, 1); LDBG_ADD(4, LDBG_NOW() - te0); }
+        (void)te0;
         double St = tot[c_reso * 16 + c_reso];
         if (bad_size) St = NAN;
+        if (sync_lost) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }   // (a bounded wait ran out)
         if (first) {
           if (P == 0) { status = CTR_STATUS_OUT_OF_BOUNDS; failed = true; }
           else if (!isfinite(St)) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
@@ -1003,7 +1141,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         };
         // ---- conjugate gradients on the free variables: (B + mu D) x = g ----------------------
         // r, z, p, A p live in LDS while they fit (the row tiles are idle during a solve)
-        const unsigned long long tc0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long tc0 = LDBG_NOW();
         const bool cg_lds = 4 * W.nvp <= LW * WAVE * LRS;
         double* rs = cg_lds ? smem + SmemL::o_rows : rs_g;
         double* zs = cg_lds ? rs + W.nvp : zs_g;
@@ -1026,9 +1164,10 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         int cg_it = 0;
         for (int ci = 0; ci < cg_max && !cg_fail && rz[0] > cg_tol2 * rz0 && rz[0] > 0.; ++ci) {
           ++cg_it;
-          const unsigned long long tm0 = __builtin_amdgcn_s_memrealtime();
+          const unsigned long long tm0 = LDBG_NOW();
           const double pAp = matvec(ps, Aps, tl, ol, mu, nwt, fre);
-          if (tid == 0) atomicAdd(&g_large_dbg[3], __builtin_amdgcn_s_memrealtime() - tm0);
+          if (tid == 0) LDBG_ADD(3, LDBG_NOW() - tm0);
+          (void)tm0;
           if (!(pAp > 0.) || !isfinite(pAp)) { cg_fail = true; break; }   // not positive definite
           const double alpha = rz[0] / pAp;
           for (int i = tid; i < n; i += LT)
@@ -1051,11 +1190,8 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
           if (tid == 0)
             for (int a = 0; a < NS; ++a) ps[a] = zs[a] + beta * ps[a];
         }
-        if (tid == 0) {
-          atomicAdd(&g_large_dbg[0], 1ull);
-          atomicAdd(&g_large_dbg[1], (unsigned long long)cg_it);
-          atomicAdd(&g_large_dbg[5], __builtin_amdgcn_s_memrealtime() - tc0);
-        }
+        if (tid == 0) { LDBG_ADD(0, 1); LDBG_ADD(1, cg_it); LDBG_ADD(5, LDBG_NOW() - tc0); }
+        (void)tc0; (void)cg_it;
         if (cg_fail) continue;
         __syncthreads();
         // projected trial point
@@ -1135,6 +1271,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
   }
 
   __syncthreads();
+  if (tid == 0) st_agent(&sy[LSY_EXIT], (unsigned long long)(unsigned)epoch);   // the helpers may leave
   const bool ok = status == CTR_STATUS_OK;
   if (ok)
     for (int e = tid; e < n * NP; e += LT) pout[e] = cur[(e / NP) * CTR_MAX_PARAMS + (e % NP)];

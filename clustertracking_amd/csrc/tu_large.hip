@@ -27,7 +27,8 @@ KernelInfo ctr_large_kernel(int ndim, int iso, int lp) {
   return iso ? one<3, true, false>() : one<3, false, false>();
 }
 
-// diagnostic, not part of include/ctrefine.h: totals since the last reset
+#ifdef CTR_STAMPS
+// diagnostic build only (make stamps), not part of include/ctrefine.h: totals since the last reset
 extern "C" int ctr_debug_large_counters(unsigned long long* out8, int reset) {
   if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_large_dbg), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
   if (reset) {
@@ -36,3 +37,4 @@ extern "C" int ctr_debug_large_counters(unsigned long long* out8, int reset) {
   }
   return 0;
 }
+#endif

@@ -166,6 +166,13 @@ def check_solver_specific(name, res, A, B, pos_columns):
     return n_checked
 
 
+# The ring's objective is NOT continuous (r2_*_safe, fitfunc.py:20-26: a pixel within one pixel of a
+# centre drops out of the sum): in ring_2d_noisy one fitted centre sits 1.00005 px from a pixel,
+# the objective jumps by 1 % across that line and either minimiser stops against it on its side
+# (3e-5 px apart, costs equal to 1e-6 relative).  (position px, cost, other columns rtol)
+LOOSE = {'ring_2d_noisy': (1e-4, 1e-7, 1e-3)}
+
+
 def oracle_runner(n_threads=1):
     import ctr_oracle
     return lambda p, b: ctr_oracle.run_batch(p, b, n_threads)

@@ -62,8 +62,9 @@ def test_golden_case_engine_vs_oracle_and_reference(engine, oracle, name):
     better = ok & (res['cost'].values < B['cost'].values - 1e-7)
     assert len(set(res['cluster'].values[better])) <= BETTER_MINIMUM.get(name, 0)
     rows = ok & ~better
-    assert np.abs(res[pc].values - B[pc].values)[rows].max() < 1e-6
-    assert_allclose(res['cost'].values[rows], B['cost'].values[rows], atol=1e-9)
+    pos_tol, cost_tol, _ = _cases.LOOSE.get(name, (1e-6, 1e-9, 1e-6))
+    assert np.abs(res[pc].values - B[pc].values)[rows].max() < pos_tol
+    assert_allclose(res['cost'].values[rows], B['cost'].values[rows], atol=cost_tol)
     rmse_A = np.sqrt(np.mean((res[pc].values - A[pc].values)[rows] ** 2))
     rmse_AB = np.sqrt(np.mean((A[pc].values - B[pc].values)[rows] ** 2))
     assert rmse_A <= max(1.5 * rmse_AB, 1e-5)

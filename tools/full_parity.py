@@ -22,6 +22,18 @@ def compare(pos, cost, status, z, tag, truth=None, order=None):
     dmax_c = np.maximum.reduceat(np.abs(d).max(1), off[:-1])
     rel = np.abs(cost - rcost) / np.abs(rcost)
     same = ok & (rel <= 1e-5)
+    # two features that trade places at the same cost (the masks follow the labels, so this
+    # happens only where the two masks hold the same pixels): compared under the best assignment
+    d_lab = d.copy()
+    n_swapped = 0
+    import itertools
+    for c in np.flatnonzero(same & (dmax_c > 1e-3) & (n_per <= 6)):
+        sl = slice(off[c], off[c + 1])
+        best = min(itertools.permutations(range(n_per[c])),
+                   key=lambda pm: np.abs(pos[sl] - rpos[sl][list(pm)]).max())
+        if list(best) != list(range(n_per[c])):
+            n_swapped += 1
+            d_lab[sl] = pos[sl] - rpos[sl][list(best)]
     out = {
         "clusters": int(len(cost)), "both_fit": int(ok.sum()),
         "failed_here_not_there": int(((status != 0) & (rstat == 0)).sum()),
@@ -30,6 +42,9 @@ def compare(pos, cost, status, z, tag, truth=None, order=None):
         "max_unfiltered_px": float(np.abs(d[rows_ok]).max()),
         "rmse_same_minimum_px": float(np.sqrt(np.mean(d[np.repeat(same, n_per)] ** 2))),
         "max_same_minimum_px": float(np.abs(d[np.repeat(same, n_per)]).max()),
+        "clusters_same_cost_labels_swapped": n_swapped,
+        "rmse_same_minimum_best_labels_px": float(np.sqrt(np.mean(d_lab[np.repeat(same, n_per)] ** 2))),
+        "max_same_minimum_best_labels_px": float(np.abs(d_lab[np.repeat(same, n_per)]).max()),
         "clusters_cost_differs_1e-5": int((ok & ~same).sum()),
         "of_which_reference_lower": int((ok & ~same & (rcost < cost)).sum()),
         "of_which_engine_lower": int((ok & ~same & (cost < rcost)).sum()),
