@@ -100,6 +100,16 @@ def algorithmic_flops(problem, hb, n_iter):
     with the MEASURED iteration counts.  Per iteration of a cluster of n features (d = ndim,
     p = mask pixels of a feature, P = union pixels, taken as n p: overlaps make it smaller):
       flops_it = sum_i p (6 d + 8) + P nv (nv + 1) + 2 P nv + 2 P + nv^3 / 3,  exps_it = sum_i p.
+    Clusters of the large-cluster path (> 64 features or > 127 variables) have a BLOCK-SPARSE
+    normal matrix (two features couple only where their masks overlap) and an iterative solve;
+    their count is sparse too, and a lower bound:
+      flops_it = n p (6 d + 8)                                    model and Jacobian rows
+               + n p (npf (npf + 1) + 2 npf + 2 npf ns + 2)       diagonal blocks, J^T r, shared rows, cost
+               + sum over overlapping pairs of p_ij 2 npf^2       the pair blocks (p_ij = pixels in both masks,
+                                                                  from the overlap volume of the two ellipsoids
+                                                                  at the start positions)
+               + 2 nnz                                            ONE product with the matrix (the solve is
+                                                                  conjugate gradients: ~100 products, not counted)
     Returns (flops, exps, {cluster size: (clusters, mean iterations)})."""
     d = int(problem.ndim)
     r = [int(problem.radius[a]) for a in range(d)]
@@ -107,9 +117,29 @@ def algorithmic_flops(problem, hb, n_iter):
     p = int((sum(g ** 2 for g in grids) <= 1.).sum())       # refine.py:43-44, centred mask
     n = np.diff(hb.feat_offset).astype(np.int64)
     modes = [int(problem.modes[k]) for k in range(int(problem.n_params))]
-    nv = sum((n if m == 1 else (1 if m != 0 else 0)) for m in modes)
+    npf = sum(1 for m in modes if m == 1)
+    ns = sum(1 for m in modes if m not in (0, 1))
+    nv = ns + n * npf
     P = n * p
-    flops_it = n * p * (6 * d + 8) + P * nv * (nv + 1) + 2 * P * nv + 2 * P + nv ** 3 / 3.
+    flops_it = (n * p * (6 * d + 8) + P * nv * (nv + 1) + 2 * P * nv + 2 * P + nv ** 3 / 3.).astype(np.float64)
+    large = (n > 64) | (nv > 127)
+    if large.any():
+        from scipy.spatial import cKDTree
+        for c in np.flatnonzero(large):
+            sl = slice(hb.feat_offset[c], hb.feat_offset[c + 1])
+            scaled = hb.params[sl, 2:2 + d] / (2. * np.asarray(r, dtype=np.float64))
+            pairs = cKDTree(scaled).query_pairs(1.0, output_type='ndarray')
+            delta = 2. * np.sqrt(((scaled[pairs[:, 0]] - scaled[pairs[:, 1]]) ** 2).sum(1)) if len(pairs) else np.zeros(0)
+            # common volume of two equal balls at centre distance delta (in radii), as a fraction
+            # of one ball (3D) / of one disc (2D)
+            if d == 3:
+                frac = 1. - 0.75 * delta + delta ** 3 / 16.
+            else:
+                frac = (2. * np.arccos(delta / 2.) - 0.5 * delta * np.sqrt(4. - delta ** 2)) / np.pi
+            p_pairs = float((p * np.clip(frac, 0., 1.)).sum())
+            nnz = n[c] * npf * npf + 2 * len(pairs) * npf * npf + 2 * n[c] * npf * ns + ns * ns
+            flops_it[c] = (n[c] * p * (6 * d + 8) + n[c] * p * (npf * (npf + 1) + 2 * npf + 2 * npf * ns + 2) +
+                           p_pairs * 2 * npf * npf + 2 * nnz)
     it = n_iter.astype(np.float64)
     by_size = {}
     for size in np.unique(n):
@@ -423,7 +453,16 @@ def main():
             # rows are its results, the others' rows finite positions
             slot_l = (step_no[0] - 1) % nfl
             last = [torch.from_numpy(inbox.read_rows(r, slot_l, counts[r])) for r in range(world)]
-            seq_ok = bool((inbox.read_seq()[:, slot_l] == step_no[0]).all())
+            # EVERY slot: it must hold the number of the last step that was mapped to it, and finite
+            # rows from every rank (nothing reads or acknowledges the slots during the timed region:
+            # a consumer on rank 0 polls seq; reusing a slot needs its acknowledgement, ctrefine.h)
+            seq = inbox.read_seq()
+            seq_ok = True
+            for sl_i in range(min(nfl, step_no[0])):
+                want = step_no[0] - ((step_no[0] - 1 - sl_i) % nfl)
+                seq_ok = seq_ok and bool((seq[:, sl_i] == want).all())
+                for r in range(world):
+                    seq_ok = seq_ok and bool(np.isfinite(inbox.read_rows(r, sl_i, counts[r])[:, 2:4]).all())
         else:
             last = gather_bufs[(step_no[0] - 1) % nfl] if per_step_gather else gather_buf
             seq_ok = True
@@ -491,6 +530,16 @@ def main():
             traffic = tj['refine_kernels']['bytes_corrected']
             traffic_source = "committed profile (%s), not this run" % tj.get('profile', 'profiles/traffic_cfg2.json')
         flops, exps, by_size = algorithmic_flops(prep.problem, hb, hb.n_iter)
+        # engine vs the reference's algorithm over the WHOLE workload (all 41 033 clusters, SLSQP with
+        # the default and with a converged tolerance): tools/full_parity.py on the GPU box, committed
+        full_parity = None
+        pf = os.path.join(ROOT, 'profiles', 'r03_parity_full_cfg2.json')
+        if args.workload == 'cfg2' and args.frames == 256 and shard == 0 and os.path.exists(pf):
+            pj = json.load(open(pf))
+            full_parity = {"source": "committed profile profiles/r03_parity_full_cfg2.json (tools/full_parity.py), not this run"}
+            for key in ('vs_reference_algorithm_default_tol_1e-6', 'vs_reference_algorithm_converged_tol_1e-14',
+                        'reference_A_vs_B'):
+                full_parity[key] = {k2: v2 for k2, v2 in pj[key].items() if k2 != 'clusters_above_1e-3_px'}
         fp64_peak = 78.6     # TFLOP/s, FP64 vector (MI355X_MICROARCH.md / SURVEY.md 8d)
         valu = None
         vf = os.path.join(ROOT, 'profiles', 'valu_cfg2.json')
@@ -507,6 +556,7 @@ def main():
             "features_per_s": value * n_feat / max(n_fits, 1),
             "failed_clusters": n_fail,
             "mean_solver_iterations": mean_iters,
+            "parity_full_workload": full_parity,
             "roofline": {"bound": "hbm", "kernel": "refine stage: refine_small_kernel<2,1|2> + refine_block_kernel<2,iso,NT,W> (concurrent streams)",
                          "achieved": alg_bytes / rf / 1e9, "peak": peak, "unit": "GB/s",
                          "frac": alg_bytes / rf / 1e9 / peak, "traffic": traffic,

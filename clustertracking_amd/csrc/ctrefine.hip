@@ -529,6 +529,12 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
   k.params_std = b->params_std;
   k.fmax = h->d_fmax;
   k.lp_w = plan->lowpass ? plan->d_lp_w : nullptr;
+  k.cg_tol2_far = 1e-8;    // (1e-12: +45 % solve time, the same fit; 1e-6: the iteration takes another path)
+  k.cg_tol2_near = 1e-22;
+  if (const char* e = std::getenv("CTR_LARGE_CG_TOL2")) {   // (measurements: "far,near")
+    double a = 0., b = 0.;
+    if (std::sscanf(e, "%lf,%lf", &a, &b) == 2 && a > 0. && b > 0.) { k.cg_tol2_far = a; k.cg_tol2_near = b; }
+  }
   for (int a = 0; a < 3; ++a) k.lp_half[a] = plan->lp_half[a];
   const int di = p.ndim == 3 ? 1 : 0, ii = p.isotropic ? 1 : 0;
   // The bins are independent: the big bin of singles runs on the caller's

@@ -41,6 +41,9 @@ struct KArgs {
   // nullptr = no lowpass.  Only the LP instantiations of the block kernel read them.
   int32_t lp_half[3];
   const double* lp_w;
+  // large-cluster kernel: squared relative residual (preconditioned norm) at which its conjugate
+  // gradients stop, far from / near the minimum (large_kernel.h)
+  double cg_tol2_far, cg_tol2_near;
 };
 
 constexpr int LP_STRIDE = 40;   // >= 2 * 16 + 1 taps (CTR_MAX_NOISE_SIZE = 4)

@@ -940,16 +940,20 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
           const double* tl = tiles_swapped ? tileB : tileA;
           for (int i = tid; i < nv; i += LT) v[i] = vt[i];
           // gradient J^T r, Marquardt diagonal, second-order entries at the new point
+          // (Marquardt diagonal: diag(J^T J), 1 where that vanishes -- a feature whose signal sits
+          //  on its bound 0 has no position derivatives -- as in oracle solve() and block_kernel.h)
           if (tid < NS) {
             g[tid] = tot[(c_sho + tid) * 16 + c_reso];
-            Dm[tid] = tot[(c_sho + tid) * 16 + c_sho + tid];
+            const double dd0 = tot[(c_sho + tid) * 16 + c_sho + tid];
+            Dm[tid] = dd0 > 1e-300 ? dd0 : 1.;
           }
           for (int i = tid; i < n; i += LT) {
             const double* t = tl + (size_t)i * 256;
             const int b0 = NS + i * NPF;
             for (int a = 0; a < NPF; ++a) {
               g[b0 + a] = t[(c_own + a) * 16];
-              Dm[b0 + a] = t[(c_own + a) * 16 + c_own + a];
+              const double dd0 = t[(c_own + a) * 16 + c_own + a];
+              Dm[b0 + a] = dd0 > 1e-300 ? dd0 : 1.;
             }
             if (newton_on) {
               // block_kernel.h / oracle eval_cluster: d2res/ds dpos_a = g_pos_a / s,
@@ -1156,10 +1160,12 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         for (int i = tid; i < nv; i += LT) ps[i] = zs[i];
         const double rz0 = rz[0];
         bool cg_fail = !(rz0 >= 0.) || !isfinite(rz0);
-        // Inexact steps while the iteration is far from the minimum (relative residual 1e-6 in
-        // the preconditioned norm), 1e-11 once the accepted steps are small: the convergence
-        // test looks at steps of 1e-9 relative size, and the fast exit at their ratio.
-        const double cg_tol2 = (last_acc && prev_step < 1e-4) ? 1e-22 : 1e-12;
+        // Inexact steps (inexact Newton): relative residual 1e-4 in the preconditioned norm while the
+        // iteration is far from the minimum, 1e-11 once the accepted steps are below 1e-4 (the
+        // convergence test looks at steps of 1e-9 relative size, and the fast exit at their ratio).
+        // Measured on a 500-feature stack: 1e-6 instead of 1e-4 costs 45 % more solve time for the
+        // same fit (2e-7 px), 1e-3 sends the re-window rounds down another path.
+        const double cg_tol2 = (last_acc && prev_step < 1e-4) ? k.cg_tol2_near : k.cg_tol2_far;
         const int cg_max = nv < 400 ? nv + 20 : 420;
         int cg_it = 0;
         for (int ci = 0; ci < cg_max && !cg_fail && rz[0] > cg_tol2 * rz0 && rz[0] > 0.; ++ci) {

@@ -55,7 +55,8 @@ enum {
   CTR_DTYPE_F64 = 5
 };
 
-/* radial profile (fitfunc.py:195-204); only GAUSS is implemented */
+/* radial profile (fitfunc.py:112-146,195-204): GAUSS, RING ('thickness' column) and DISC ('disc_size'
+ * column) are implemented; INV_SERIES is reserved (CTR_ERR_UNSUPPORTED) */
 enum { CTR_FIT_GAUSS = 0, CTR_FIT_RING = 1, CTR_FIT_DISC = 2, CTR_FIT_INV_SERIES = 3 };
 
 /* parameter modes (fitfunc.py:9-11); 2 ('global') is rejected: it couples all
@@ -156,7 +157,8 @@ typedef struct ctr_batch {
                                   parameters, failed clusters and a Hessian that is not positive
                                   definite.  Every parameter mode (second derivatives w.r.t.
                                   signal, centres and sizes).  NaN for clusters of the
-                                  large-cluster path (> 64 features). */
+                                  large-cluster path (> 64 features) and for the ring / disc
+                                  profiles (the second derivatives are the gaussian's). */
   double* result_rows;         /* [N, n_params + 1] or NULL: params_out and, last column, the cost of
                                   the row's cluster -- the rows of the result table (refine.py:426-427)
                                   in one block, written when the batch is done: what a pipeline sends
@@ -167,7 +169,10 @@ typedef struct ctr_batch {
   int64_t* done_flag;          /* NULL, or where ctr_refine_batch_device stores done_value (one
                                   8-byte store from a kernel of its own, queued last on the call's
                                   stream: after every output above is written); device or peer
-                                  memory like result_rows: a consumer polls it per batch */
+                                  memory like result_rows: a consumer polls it per batch.  There is
+                                  no flow control: a caller that reuses result_rows / done_flag for a
+                                  later batch must have its consumer's acknowledgement first (or one
+                                  slot per batch in flight, as bench.py's inbox) */
   int64_t done_value;
 } ctr_batch;
 
