@@ -141,3 +141,47 @@ def load():
     ct.quiet()
     _loaded = ct
     return ct
+
+
+class _NumpyCompat(object):
+    """``np`` as the reference's ``artificial.draw_feature`` needs it under NumPy 2: the one call
+    that fails there, ``np.array(coords)`` on the SPARSE meshgrid (artificial.py:139: arrays of
+    shapes (n,1) and (1,m), an inhomogeneous list since NumPy 1.24), gets the grids broadcast
+    against each other first -- the same values the old object-array arithmetic summed.  Every
+    other attribute is NumPy's."""
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    @staticmethod
+    def array(obj, *args, **kwargs):
+        if isinstance(obj, (list, tuple)) and len(obj) > 1 and all(isinstance(o, np.ndarray) for o in obj) \
+                and len({o.shape for o in obj}) > 1:
+            obj = np.broadcast_arrays(*obj)
+        return np.array(obj, *args, **kwargs)
+
+
+class ListIndexArray(np.ndarray):
+    """An image the reference can index with a LIST of slices (artificial.py:141 ``image[rect] +=``;
+    an IndexError on NumPy >= 1.23): the list is turned into the tuple it meant."""
+
+    def __getitem__(self, key):
+        return np.ndarray.__getitem__(self, tuple(key) if isinstance(key, list) else key)
+
+    def __setitem__(self, key, value):
+        np.ndarray.__setitem__(self, tuple(key) if isinstance(key, list) else key, value)
+
+
+def reference_draw_feature(image, position, size, max_value, feat_func='gauss', **kwargs):
+    """The REFERENCE's ``artificial.draw_feature`` (artificial.py:81-141) run as it is on a copy of
+    ``image`` (see the two classes above for what NumPy 2 needs); returns the drawn image."""
+    ct = load()
+    import clustertracking.artificial as ref_art
+    ref_art.np = _NumpyCompat()
+    try:
+        im = np.array(image).view(ListIndexArray)
+        ref_art.draw_feature(im, position, size, max_value, feat_func, **kwargs)
+    finally:
+        ref_art.np = np
+    return np.asarray(im)
+
