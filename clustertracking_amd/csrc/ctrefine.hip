@@ -627,6 +627,9 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     }
     int64_t per_cluster = 512 / cnt;               // workgroups per cluster, leader included
     per_cluster = per_cluster < 1 ? 1 : (per_cluster > 8 ? 8 : per_cluster);
+    // (several batches in flight fill the machine by themselves: a waiting helper would only hold
+    //  the compute unit that another batch's leader needs)
+    if ((p.flags & CTR_FLAG_THROUGHPUT) != 0) per_cluster = 1;
     if (const char* e = std::getenv("CTR_LARGE_WORKGROUPS")) {   // (measurements)
       const long v = std::strtol(e, nullptr, 10);
       if (v >= 1 && v <= 16) per_cluster = v;

@@ -1,4 +1,4 @@
-"""Turn what tools/profile_r2.sh left under gpurun_out/<round>/ into the files of profiles/
+"""Turn what tools/profile_r3.sh left under gpurun_out/<round>/ into the files of profiles/
 (<round>_*: kernel stats with 8 batches in flight and with one, bench lines, counters per launch,
 traffic_cfg2.json, valu_cfg2.json).
 
@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 os.chdir(ROOT)
-RND = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+RND = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 SRC = 'gpurun_out/%s' % RND
 
 
@@ -57,7 +57,7 @@ fm_w = [sum(v) / len(v) for k, v in tot['WRITE_SIZE'].items() if 'frame_max_kern
 t = json.load(open('profiles/traffic_cfg2.json'))
 t['profile'] = 'profiles/%s_pmc_per_launch.csv' % RND
 t['source'] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (profiles/%s_pmc_per_launch.csv), "
-               "per launch; tools/profile_r2.sh" % RND)
+               "per launch; tools/profile_r3.sh" % RND)
 t['frame_max_kernel'].update(FETCH_SIZE_KB=fm_f, WRITE_SIZE_KB=fm_w, bytes_corrected=(2 * fm_f + fm_w) * 1024)
 t['refine_kernels'].update(FETCH_SIZE_KB=f, WRITE_SIZE_KB=w, bytes_corrected=(2 * f + w) * 1024)
 json.dump(t, open('profiles/traffic_cfg2.json', 'w'), indent=1)
@@ -83,7 +83,7 @@ clock = 2.4e9
 simds = 256 * 4
 valu = {
     "workload": "cfg2, 256 frames, one batch at a time (bench.py --in-flight 1), default scheduling",
-    "source": "profiles/%s_pmc_sq_per_launch.csv (rocprofv3 --pmc, five passes; tools/profile_r2.sh)" % RND,
+    "source": "profiles/%s_pmc_sq_per_launch.csv (rocprofv3 --pmc, five passes; tools/profile_r3.sh)" % RND,
     "valu_wave_instructions_per_launch": valu_insts,
     "sq_active_inst_valu_quad_cycles": active,
     "refine_stage_s_one_batch_alone": step_s,
@@ -100,7 +100,8 @@ json.dump(valu, open('profiles/valu_cfg2.json', 'w'), indent=1)
 shutil.copy(latest('%s/prof/*/*kernel_stats.csv' % SRC), 'profiles/%s_kernel_stats.csv' % RND)
 shutil.copy(latest('%s/prof_inflight1/*/*kernel_stats.csv' % SRC), 'profiles/%s_kernel_stats_inflight1.csv' % RND)
 for fn, o in (('bench', '%s_bench.json' % RND), ('bench_inflight1', '%s_bench_inflight1.json' % RND),
-              ('bench_cfg5', '%s_bench_cfg5.json' % RND)):
+              ('bench_cfg5', '%s_bench_cfg5.json' % RND), ('bench_cfg3', '%s_bench_cfg3.json' % RND),
+              ('bench_cfg3_inflight1', '%s_bench_cfg3_inflight1.json' % RND)):
     path = '%s/%s.json' % (SRC, fn)
     if not os.path.exists(path):
         continue
@@ -111,3 +112,35 @@ for fn, o in (('bench', '%s_bench.json' % RND), ('bench_inflight1', '%s_bench_in
           d.get('failed_clusters'), 'in flight', d.get('batches_in_flight'), d.get('in_flight_results_identical'))
 print('refine kernels: FETCH %.0f KB WRITE %.0f KB -> %.1f MB per step' % (f, w, (2 * f + w) * 1024 / 1e6))
 print('VALU busy %.3f, issue bound %.3f ms of %.3f ms' % (valu['valu_busy_frac'], valu['valu_issue_bound_s'] * 1e3, step_s * 1e3))
+
+# ---- cfg 3 at its stated density: the large-cluster kernel, one batch at a time ---------------------
+if glob.glob('%s/cfg3_prof/*/*kernel_stats.csv' % SRC):
+    shutil.copy(latest('%s/cfg3_prof/*/*kernel_stats.csv' % SRC), 'profiles/%s_cfg3_kernel_stats.csv' % RND)
+    with open('profiles/%s_cfg3_pmc_per_launch.csv' % RND, 'w') as fo:
+        fo.write('counter,kernel,launches,mean_value\n')
+        for d in ('cfg3_pmc_fetch', 'cfg3_pmc_write', 'cfg3_pmc_sq1', 'cfg3_pmc_sq2'):
+            if not glob.glob('%s/%s/*/*counter_collection.csv' % (SRC, d)):
+                continue
+            for cname, per in per_kernel(d).items():
+                for k, v in per.items():
+                    if 'refine_' in k or 'frame_max' in k:
+                        fo.write('%s,"%s",%d,%.3f\n' % (cname, k, len(v), sum(v) / len(v)))
+    print('cfg3 profiles written')
+# ---- what FETCH_SIZE counts (tools/fetch_calib.hip) ---------------------------------------------------
+if glob.glob('%s/fetch_calib/*/*counter_collection.csv' % SRC):
+    per = per_kernel('fetch_calib')['FETCH_SIZE']
+    n = 64 << 20
+    cal = {"buffer_bytes": n, "lines_128B": n // 128, "source": "tools/fetch_calib.hip under rocprofv3 --pmc FETCH_SIZE (tools/profile_r3.sh)"}
+    for k, v in per.items():
+        name = k.split('(')[0]
+        cal[name] = {"FETCH_SIZE_KB_per_launch": sum(v) / len(v), "launches": len(v)}
+    s16 = [v for k, v in cal.items() if k.startswith('stream16')][0]['FETCH_SIZE_KB_per_launch'] * 1024
+    l1 = [v for k, v in cal.items() if k.startswith('line1')][0]['FETCH_SIZE_KB_per_launch'] * 1024
+    w13 = [v for k, v in cal.items() if k.startswith('window13')][0]['FETCH_SIZE_KB_per_launch'] * 1024
+    frames = n // (512 * 512)
+    cal["reported_over_bytes_touched_stream16"] = s16 / n
+    cal["reported_bytes_per_line_line1"] = l1 / (n // 128)
+    cal["reported_bytes_per_distinct_line_window13"] = w13 / (frames * 31 * 13 * 4)
+    json.dump(cal, open('profiles/%s_fetch_calibration.json' % RND, 'w'), indent=1)
+    print('FETCH_SIZE calibration:', {k: v for k, v in cal.items() if k.startswith('reported')})
+
