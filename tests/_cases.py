@@ -20,7 +20,7 @@ from clustertracking_amd import constraints as cons  # noqa: E402
 def case_names():
     # refine fixtures only (link_cases.npz belongs to tests/test_link.py)
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, '*.npz'))
-                  if not os.path.basename(p).startswith(('link_', 'cfg3_500', 'cfg2_full')))
+                  if not os.path.basename(p).startswith(('link_', 'cfg3_500', 'cfg2_full', 'draw_')))
 
 
 class Case(object):
