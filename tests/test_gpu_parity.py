@@ -385,7 +385,7 @@ def test_result_rows_block_written_by_the_engine(engine):
     n_bytes = 2 * n * width * 8 + 2 * 8
     base, handle = engine.ipc_alloc(n_bytes)
     try:
-        assert len(handle) == 64
+        assert len(handle) == _abi.IPC_HANDLE_BYTES
         seq_addr = base + 2 * n * width * 8
         engine.ipc_probe(seq_addr + 8, -5)                      # a store from a kernel
         assert engine.ipc_read(seq_addr, (2,), np.int64).tolist() == [0, -5]
