@@ -22,7 +22,10 @@
 #ifndef CTREFINE_LARGE_KERNEL_H
 #define CTREFINE_LARGE_KERNEL_H
 
-constexpr int LW = 8;              // wavefronts per workgroup (512 threads: 256 VGPRs per lane -- with 1024
+#ifndef CTR_LARGE_WAVES
+#define CTR_LARGE_WAVES 8
+#endif
+constexpr int LW = CTR_LARGE_WAVES; // wavefronts per workgroup (512 threads: 256 VGPRs per lane -- with 1024
                                    // the kernel spilled 0.8-1.3 KB per lane; two workgroups fit a CU's LDS)
 constexpr int LT = LW * WAVE;      // threads
 constexpr int LRS = 17;            // row stride of a wave's LDS tile (odd: conflict-free ds_write_b64)
@@ -30,8 +33,9 @@ constexpr int LRED = 12;           // values per wave in the reduction scratch
 constexpr int LQT = 9;             // second-order entries per feature (block_kernel.h: QT)
 
 struct SmemL {
-  static constexpr int o_rows = 0;                       // LW row tiles of 64 x LRS
-  static constexpr int o_red = o_rows + LW * WAVE * LRS; // reduction scratch [LW][LRED]
+  static constexpr int o_rows = 0;                       // LW row tiles of 64 x LRS; the CG's vectors during a solve
+  static constexpr int n_rows = LW * WAVE * LRS > 8 * WAVE * LRS ? LW * WAVE * LRS : 8 * WAVE * LRS;
+  static constexpr int o_red = o_rows + n_rows;          // reduction scratch [LW][LRED]
   static constexpr int o_tot = o_red + LW * LRED;        // 256 sums over the features of the tiles
   static constexpr int o_sh = o_tot + 256;               // shared-variable scratch: 8 x 8 + 6 x 8
   static constexpr int total = o_sh + 64 + 48;
@@ -1146,7 +1150,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         // ---- conjugate gradients on the free variables: (B + mu D) x = g ----------------------
         // r, z, p, A p live in LDS while they fit (the row tiles are idle during a solve)
         const unsigned long long tc0 = LDBG_NOW();
-        const bool cg_lds = 4 * W.nvp <= LW * WAVE * LRS;
+        const bool cg_lds = 4 * W.nvp <= SmemL::n_rows;
         double* rs = cg_lds ? smem + SmemL::o_rows : rs_g;
         double* zs = cg_lds ? rs + W.nvp : zs_g;
         double* ps = cg_lds ? zs + W.nvp : ps_g;

@@ -28,7 +28,7 @@ __global__ void line1(const unsigned char* __restrict__ p, unsigned* sink, size_
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned acc = 0;
   if (i < nlines) acc = p[i * 128 + (i % 128)];
-  if (acc == 0x1234u) *sink = acc;
+  if (acc == 77u) *sink = acc;   // (never true: the buffer holds 1s; keeps the load)
 }
 
 // frames of 512 x 512 bytes; wave w takes window w: origin (16 * (w / 32) % 496, 16 * (w % 32)) of
@@ -42,7 +42,7 @@ __global__ void window13(const unsigned char* __restrict__ p, unsigned* sink, si
     const size_t y0 = 16 * (r / 32), x0 = 16 * (r % 32);
     acc = p[frame * 512 * 512 + (y0 + l / 13) * 512 + x0 + l % 13];
   }
-  if (acc == 0x1234u) *sink = acc;
+  if (acc == 77u) *sink = acc;   // (never true: the buffer holds 1s; keeps the load)
 }
 
 int main() {
