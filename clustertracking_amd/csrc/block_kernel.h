@@ -255,8 +255,28 @@ __device__ unsigned long long g_stamps[16];
 // pixel value is the filtered one, computed from the raw frame where it is needed.
 // FIT: the radial profile (CTR_FIT_GAUSS / RING / DISC, device_common.h:profile_dev); ring and disc
 // carry one more parameter column (thickness / disc_size) and iterate with the Gauss-Newton model.
+// Minimum wavefronts per SIMD asked of the compiler (the register budget) for the instantiations
+// of the throughput scheduling (2D, fewest wavefronts per cluster: W = 2 for NT <= 2, 1 above).
+// NT = 1 (3-4 features): 3 -- 168 VGPRs + 272 B of scratch instead of 231 + 100 at 2 per SIMD:
+// +6 % on cfg 2 with ten batches in flight (interleaved A/B, tools/ab_bench.sh: 48.4 -> 51.4 M fits/s;
+// 4 per SIMD: 128 VGPRs + 484 B, -8 %).  The kernel waits on dependent FP64 chains; a third
+// wavefront per SIMD hides more of them than the spills cost.
+#ifndef CTR_OCC_NT1
+#define CTR_OCC_NT1 3
+#endif
+#ifndef CTR_OCC_NT2
+#define CTR_OCC_NT2 1
+#endif
+#ifndef CTR_OCC_NT34
+#define CTR_OCC_NT34 1
+#endif
+constexpr int block_occ(int nt, int w, bool cons, bool lp, int fit) {
+  return (cons || lp || fit != 0) ? 1 : (nt == 1 && w == 2) ? CTR_OCC_NT1 : (nt == 2 && w == 2) ? CTR_OCC_NT2
+       : ((nt == 3 || nt == 4) && w == 1) ? CTR_OCC_NT34 : 1;
+}
 template <int ND, bool ISO, int NT, int W, bool CONS, bool LP = false, int FIT = 0>
-__global__ void __launch_bounds__(WAVE * W) refine_block_kernel(const KArgs k) {
+__global__ void __launch_bounds__(WAVE * W, (block_occ(NT, W, CONS, LP, FIT)))
+refine_block_kernel(const KArgs k) {
 #ifdef CTR_STAMPS
   unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
 #endif
