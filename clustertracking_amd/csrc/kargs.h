@@ -58,10 +58,12 @@ struct KernelInfo {
 
 // ---- workspace of one large cluster (large_kernel.h), in doubles ---------------------------
 constexpr int LARGE_MAXNB = 48;   // neighbours (features with overlapping mask ellipsoids) per feature
+constexpr int LARGE_AGG = 4;      // features per aggregate of the preconditioner
+constexpr int LARGE_AGG_STRIDE = 512;   // >= (4 * 7) (4 * 7 + 1) / 2 = 406 packed entries
 
 struct LargeWs {
   long long nvp, nvp_i;   // variables / features rounded up to a multiple of 8
-  long long o_vec, o_cur, o_mco, o_fpar, o_pre, o_uq, o_tile, o_off, o_offc, o_int, o_sync, total;
+  long long o_vec, o_cur, o_mco, o_fpar, o_pre, o_uq, o_tile, o_off, o_offc, o_int, o_sync, o_pre2, o_agg, total;
 };
 
 // n features, npf per-feature and ns shared variables
@@ -81,6 +83,11 @@ __host__ __device__ inline LargeWs large_ws(int n, int npf, int ns) {
   W.o_off = o;  o += 2 * nn * LARGE_MAXNB * 64;  // accepted / trial neighbour blocks
   W.o_offc = o; o += nn * LARGE_MAXNB * npf * npf;  // accepted blocks, packed (the CG's copy)
   W.o_int = o;  o += (W.nvp_i + 2 * nn * LARGE_MAXNB + 1) / 2 + 8;   // nbcnt, nbidx, rev (int32)
+  // preconditioner aggregates (large_kernel.h): factors of up to n / 2 aggregates of <= 4 features
+  // (LARGE_AGG_STRIDE doubles each), and their tables (int32: agg_of[n], parent[n], size[n],
+  // members[4 (n / 2 + 1)], n_multi)
+  W.o_pre2 = o; o += (nn / 2 + 1) * LARGE_AGG_STRIDE;
+  W.o_agg = o;  o += (3 * W.nvp_i + 4 * (nn / 2 + 1) + 8 + 1) / 2 + 8;
   o = (o + 15) & ~15LL;
   W.o_sync = o; o += 64;                         // leader / helper words (large_kernel.h: LSY_*), zero at plan creation
   W.total = (o + 31) & ~31LL;

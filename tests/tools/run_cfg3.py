@@ -21,12 +21,15 @@ n_per = np.diff(b.feat_offset)
 print('stacks %d features %d clusters %d largest %s: %.3f s (%.0f features/s)' % (
     stacks, len(f0), b.n_clusters, np.sort(n_per)[-3:], dt, len(f0) / dt))
 import ctypes
-dbg = (ctypes.c_ulonglong * 8)()
+dbg = (ctypes.c_ulonglong * 24)()
 if hasattr(eng._lib, 'ctr_debug_large_counters') and eng._lib.ctr_debug_large_counters(dbg, 1) == 0:
     print('large path (both runs): solves %d, CG iterations %d (%.1f per solve), pixel passes %d' % (
         dbg[0], dbg[1], dbg[1] / max(dbg[0], 1), dbg[2]))
     print('  time in pixel passes %.3f s, in solves %.3f s of which matrix-vector products %.3f s (summed over clusters)' % (dbg[4] * 1e-8, dbg[5] * 1e-8, dbg[3] * 1e-8))
     print('  wave 0: feature tiles %.3f s, pair blocks %.3f s' % (dbg[6] * 1e-8, dbg[7] * 1e-8))
+    for kq, name in enumerate(('exact Hessian, converged', 'exact Hessian, not positive definite', 'J^T J, converged', 'J^T J, failed')):
+        ns, ni, ncap = dbg[8 + 4 * kq], dbg[9 + 4 * kq], dbg[10 + 4 * kq]
+        print('  %-38s %6d solves, %8d CG iterations (%.1f per solve), %d at the iteration cap' % (name, ns, ni, ni / max(ns, 1), ncap))
 print('status counts', np.bincount(b.status), 'rounds', b.n_rounds[:8], 'iters', b.n_iter[:8])
 out = np.empty_like(b.params_out); out[prep.order] = b.params_out
 ok = np.empty(len(out), bool); ok[prep.order] = np.repeat(b.status == 0, n_per)
