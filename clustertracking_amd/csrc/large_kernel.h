@@ -31,6 +31,7 @@ constexpr int LT = LW * WAVE;      // threads
 constexpr int LRS = 17;            // row stride of a wave's LDS tile (odd: conflict-free ds_write_b64)
 constexpr int LRED = 12;           // values per wave in the reduction scratch
 constexpr int LQT = 9;             // second-order entries per feature (block_kernel.h: QT)
+constexpr int LNB = 17;            // doubles per neighbour in a wavefront's LDS table (odd stride)
 
 struct SmemL {
   static constexpr int o_rows = 0;                       // LW row tiles of 64 x LRS; the CG's vectors during a solve
@@ -38,7 +39,10 @@ struct SmemL {
   static constexpr int o_red = o_rows + n_rows;          // reduction scratch [LW][LRED]
   static constexpr int o_tot = o_red + LW * LRED;        // 256 sums over the features of the tiles
   static constexpr int o_sh = o_tot + 256;               // shared-variable scratch: 8 x 8 + 6 x 8
-  static constexpr int total = o_sh + 64 + 48;
+  // per wavefront: the constants of the neighbours of the feature it is working on
+  // (LARGE_MAXNB x LNB doubles: 13 derived constants, mask centre relative to the window, index)
+  static constexpr int o_nb = o_sh + 64 + 48;
+  static constexpr int total = o_nb + LW * LARGE_MAXNB * 17;
   static constexpr size_t bytes = (size_t)total * sizeof(double);
 };
 
@@ -242,26 +246,30 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       }
       const int cnt = nbcnt[i];
       const int* nb = nbidx + (size_t)i * LARGE_MAXNB;
-      // This feature's constants in registers; neighbour l's (index, mask centre relative to the
-      // window, derived constants) in the registers of LANE l, broadcast with v_readlane when a
-      // tile needs them: read from the workspace once per feature, not once per tile and
-      // neighbour (dependent L2 round trips made a tile cost 14 us).
+      // This feature's constants in registers; its neighbours' are read from the workspace once
+      // per feature, not once per tile and neighbour (dependent L2 round trips made a tile cost
+      // 14 us).
       double fi[13];
 #pragma unroll
       for (int q2 = 0; q2 < 13; ++q2) fi[q2] = fpar[(size_t)i * FP + q2];
-      int nj = 0;
-      double nrel[ND], nf[13];
+      // neighbour l's mask centre stays in the registers of LANE l (the per-tile box test); its
+      // derived constants and index go to this wavefront's LDS table, read back with one address
+      // for all lanes (a broadcast) where a tile needs them.  (Round 2 kept all of it in lane
+      // registers and broadcast with v_readlane: 33 registers in a kernel that spills 500 bytes per
+      // lane, 32 lane reads per candidate.)
+      double nrel[ND];
+      double* nbl = smem + SmemL::o_nb + wave * (LARGE_MAXNB * LNB);
 #pragma unroll
       for (int a = 0; a < ND; ++a) nrel[a] = 0.;
-#pragma unroll
-      for (int q2 = 0; q2 < 13; ++q2) nf[q2] = 0.;
       if (lane < cnt) {
-        nj = nb[lane];
+        const int njl = nb[lane];
 #pragma unroll
-        for (int a = 0; a < ND; ++a) nrel[a] = mco[nj * 3 + a] - (double)origin[a];
+        for (int a = 0; a < ND; ++a) { nrel[a] = mco[njl * 3 + a] - (double)origin[a]; nbl[lane * LNB + 13 + a] = nrel[a]; }
 #pragma unroll
-        for (int q2 = 0; q2 < 13; ++q2) nf[q2] = fpar[(size_t)nj * FP + q2];
+        for (int q2 = 0; q2 < 13; ++q2) nbl[lane * LNB + q2] = fpar[(size_t)njl * FP + q2];
+        nbl[lane * LNB + 16] = (double)njl;
       }
+      wsync();
       const unsigned long long tf0 = LDBG_NOW();
       v4d acc = v4d{0., 0., 0., 0.};
       constexpr int NUF = ND * (ND + 1) / 2;
@@ -351,12 +359,12 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
             } else {
               double rel[ND];
 #pragma unroll
-              for (int a = 0; a < ND; ++a) rel[a] = readlane_f64(nrel[a], s2);
+              for (int a = 0; a < ND; ++a) rel[a] = nbl[s2 * LNB + 13 + a];
               covered = in_i && in_mask<ND>(idx, rel, inv_r2, radius);
-              const int j = __builtin_amdgcn_readlane(nj, s2);
+              const int j = (int)nbl[s2 * LNB + 16];
               if (covered && j < i) owner = false;
 #pragma unroll
-              for (int q2 = 0; q2 < 13; ++q2) f[q2] = readlane_f64(nf[q2], s2);
+              for (int q2 = 0; q2 < 13; ++q2) f[q2] = nbl[s2 * LNB + q2];
             }
             if (covered) {
             double r2 = 0., dd[ND], d[1 + ND + NSZ];
@@ -442,16 +450,16 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       const unsigned long long tf1 = LDBG_NOW();
       // ---- neighbour blocks: d_i d_j^T over mask i & mask j, for the neighbours j > i -------
       for (int s2 = 0; s2 < cnt; ++s2) {
-        const int j = __builtin_amdgcn_readlane(nj, s2);
+        const int j = (int)nbl[s2 * LNB + 16];
         if (j < i) continue;
         double fj[13];
 #pragma unroll
-        for (int q2 = 0; q2 < 13; ++q2) fj[q2] = readlane_f64(nf[q2], s2);
+        for (int q2 = 0; q2 < 13; ++q2) fj[q2] = nbl[s2 * LNB + q2];
         double rel_j[ND];
         int plo[ND], psz[ND], np2 = 1;
 #pragma unroll
         for (int a = 0; a < ND; ++a) {
-          rel_j[a] = readlane_f64(nrel[a], s2);
+          rel_j[a] = nbl[s2 * LNB + 13 + a];
           int l = (int)ceil(rel_j[a] - (double)radius[a]), u = (int)floor(rel_j[a] + (double)radius[a]);
           l = l < blo[a] ? blo[a] : l;
           u = u > blo[a] + bsz[a] - 1 ? blo[a] + bsz[a] - 1 : u;
