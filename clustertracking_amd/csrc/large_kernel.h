@@ -83,9 +83,11 @@ __device__ __forceinline__ bool wg_any(bool x, double* red, int lane, int wave) 
 __device__ unsigned long long g_large_dbg[24];   // [8..]: solves and CG iterations by (model, outcome), see below
 #define LDBG_ADD(slot, val) atomicAdd(&g_large_dbg[slot], (unsigned long long)(val))
 #define LDBG_NOW() __builtin_amdgcn_s_memrealtime()
+#define LDBG_CYC() __builtin_amdgcn_s_memtime()
 #else
 #define LDBG_ADD(slot, val) do {} while (0)
 #define LDBG_NOW() 0ull
+#define LDBG_CYC() 0ull
 #endif
 
 // ---- leader / helpers ---------------------------------------------------------------------------
@@ -278,6 +280,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       for (int t = 0; t < NUF; ++t) uacc[t] = 0.;
       double* row = myrows + lane * LRS;
       for (int base = 0; base < npx; base += WAVE) {
+        const unsigned long long tc_a = LDBG_CYC();
         const int q = base + lane;
         int idx[ND];
         bool in_i = false;
@@ -338,6 +341,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
             else pix = load_pixel(frame, k.frame_dtype, offp);
           }
           double res = pix - bgv;
+          const unsigned long long tc_b = LDBG_CYC();
           bool owner = true;
           double shared[CTR_MAX_PARAMS], down[1 + ND + NSZ];
 #pragma unroll
@@ -363,8 +367,14 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
               covered = in_i && in_mask<ND>(idx, rel, inv_r2, radius);
               const int j = (int)nbl[s2 * LNB + 16];
               if (covered && j < i) owner = false;
+              // (a candidate by its box that covers none of the 64 pixels: nothing to load)
+              if (__ballot(covered) != 0ull) {
 #pragma unroll
-              for (int q2 = 0; q2 < 13; ++q2) f[q2] = nbl[s2 * LNB + q2];
+                for (int q2 = 0; q2 < 13; ++q2) f[q2] = nbl[s2 * LNB + q2];
+              } else {
+#pragma unroll
+                for (int q2 = 0; q2 < 13; ++q2) f[q2] = 0.;
+              }
             }
             if (covered) {
             double r2 = 0., dd[ND], d[1 + ND + NSZ];
@@ -400,6 +410,9 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
             s2 = __builtin_ctzll(todo);
             todo &= todo - 1ull;
           }
+          const unsigned long long tc_c = LDBG_CYC();
+          if (tid == 0 && !helper) { LDBG_ADD(20, tc_b - tc_a); LDBG_ADD(21, tc_c - tc_b); }
+          (void)tc_a; (void)tc_b; (void)tc_c;
           Pown += (in_i && owner) ? 1 : 0;
           if (in_i && res == res) {   // nansum (fitfunc.py:449,483): a NaN pixel counts in P only
             const double ow = owner ? 1. : 0.;
@@ -423,6 +436,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
             }
           }
         }
+        const unsigned long long tc_d = LDBG_CYC();
         wsync();
         {
           const double* rbase = myrows + (lane >> 4) * LRS + (lane & 15);
@@ -433,6 +447,8 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
           }
         }
         wsync();
+        if (tid == 0 && !helper) { LDBG_ADD(22, LDBG_CYC() - tc_d); LDBG_ADD(23, 1); }
+        (void)tc_d;
       }
       // D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
       {
