@@ -383,6 +383,8 @@ int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
   if (other_profile) default_modes = false;
   std::vector<long long> ws_off((size_t)n_clusters, 0);
   long long ws_total = 0;
+  long long box_cap = 1;     // pixels of a mask's bounding box (large_ws)
+  for (int a = 0; a < p->ndim; ++a) box_cap *= 2 * (long long)p->radius[a] + 1;
   for (int64_t c = 0; c < n_clusters; ++c) {
     const int64_t n = (int64_t)feat_offset_host[c + 1] - feat_offset_host[c];
     if (n < 0) { delete plan; return fail(h, CTR_ERR_INVALID, "feat_offset must be non-decreasing"); }
@@ -405,10 +407,12 @@ int ctr_plan_create(ctr_handle* h, const ctr_problem* p, int64_t n_clusters,
     }
     if (bin == BIN_LARGE) {
       // the large kernel's 16-column row: [r, shared.., own.., r_o, shared_o..]
-      if (npf < 1 || 2 + 2 * nsh + npf > 16 || other_profile) bin = BIN_TOO_LARGE;
+      bool wide_mask = false;   // (its list of mask pixels packs box coordinates in 10 bits per axis)
+      for (int a = 0; a < p->ndim; ++a) wide_mask = wide_mask || p->radius[a] > 500;
+      if (npf < 1 || 2 + 2 * nsh + npf > 16 || other_profile || wide_mask) bin = BIN_TOO_LARGE;
       else {
         ws_off[(size_t)c] = ws_total;
-        ws_total += large_ws((int)n, npf, nsh).total;
+        ws_total += large_ws((int)n, npf, nsh, box_cap).total;
       }
     }
     bin_of[(size_t)c] = bin;

@@ -63,11 +63,12 @@ constexpr int LARGE_AGG_STRIDE = 512;   // >= (4 * 7) (4 * 7 + 1) / 2 = 406 pack
 
 struct LargeWs {
   long long nvp, nvp_i;   // variables / features rounded up to a multiple of 8
-  long long o_vec, o_cur, o_mco, o_fpar, o_pre, o_uq, o_tile, o_off, o_offc, o_int, o_sync, o_pre2, o_agg, total;
+  long long o_vec, o_cur, o_mco, o_fpar, o_pre, o_uq, o_tile, o_off, o_offc, o_int, o_sync, o_pre2, o_agg, o_pix, cap, total;
 };
 
 // n features, npf per-feature and ns shared variables
-__host__ __device__ inline LargeWs large_ws(int n, int npf, int ns) {
+// cap: pixels of a mask's bounding box, prod(2 radius + 1): room for a feature's list of mask pixels
+__host__ __device__ inline LargeWs large_ws(int n, int npf, int ns, long long cap) {
   LargeWs W;
   const long long nn = n, nv = ns + nn * npf;
   W.nvp = (nv + 7) & ~7LL;
@@ -88,6 +89,10 @@ __host__ __device__ inline LargeWs large_ws(int n, int npf, int ns) {
   // members[4 (n / 2 + 1)], n_multi)
   W.o_pre2 = o; o += (nn / 2 + 1) * LARGE_AGG_STRIDE;
   W.o_agg = o;  o += (3 * W.nvp_i + 4 * (nn / 2 + 1) + 8 + 1) / 2 + 8;
+  // the mask pixels of every feature, compacted (int32: box coordinates, 10 bits per axis), rebuilt
+  // every re-window round: [n] counts, then n lists of `cap` entries
+  W.cap = (cap + 63) & ~63LL;
+  W.o_pix = o;  o += (W.nvp_i + nn * W.cap + 1) / 2 + 8;
   o = (o + 15) & ~15LL;
   W.o_sync = o; o += 64;                         // leader / helper words (large_kernel.h: LSY_*), zero at plan creation
   W.total = (o + 31) & ~31LL;

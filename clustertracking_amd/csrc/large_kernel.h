@@ -143,7 +143,10 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
   const int nv = L.nv, NS = L.nshared, NPF = L.npf;
   // columns of the 16-wide row: residual, shared, own, and the "owned pixel" copies
   const int c_own = 1 + NS, c_reso = 1 + NS + NPF, c_sho = 2 + NS + NPF;
-  const LargeWs W = large_ws(n, NPF, NS);
+  long long box_cap = 1;
+#pragma unroll
+  for (int a = 0; a < ND; ++a) box_cap *= 2 * (long long)k.prob.radius[a] + 1;
+  const LargeWs W = large_ws(n, NPF, NS, box_cap);
   double* ws = ws_base + ws_off[cl];
   double *v = ws + W.o_vec, *vt = v + W.nvp, *v0 = vt + W.nvp, *lo = v0 + W.nvp, *hi = lo + W.nvp,
          *g = hi + W.nvp, *xs = g + W.nvp, *rs_g = xs + W.nvp, *zs_g = rs_g + W.nvp, *ps_g = zs_g + W.nvp,
@@ -159,6 +162,8 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
   int* nbidx = nbcnt + W.nvp_i;
   int* rev = nbidx + (size_t)n * LARGE_MAXNB;
   unsigned long long* sy = (unsigned long long*)(ws + W.o_sync);   // leader / helper words (LSY_*)
+  int* pix_cnt = (int*)(ws + W.o_pix);         // mask pixels of feature i: count, then the list
+  int* pix_list = pix_cnt + W.nvp_i;
   // aggregates of the preconditioner: strongly coupled features share one diagonal block
   double* pre2 = ws + W.o_pre2;
   int* agg_of = (int*)(ws + W.o_agg);          // multi-feature aggregate of feature i, -1: on its own
@@ -279,32 +284,39 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
 #pragma unroll
       for (int t = 0; t < NUF; ++t) uacc[t] = 0.;
       double* row = myrows + lane * LRS;
-      for (int base = 0; base < npx; base += WAVE) {
+      // the mask pixels of feature i from its list (built once per re-window round, box order):
+      // 64 of them per tile, every lane at work -- 41 % of a 9 x 17 x 17 box is mask
+      const int npl = pix_cnt[i];
+      const int* plist = pix_list + (size_t)i * W.cap;
+      for (int base = 0; base < npl; base += WAVE) {
         const unsigned long long tc_a = LDBG_CYC();
         const int q = base + lane;
         int idx[ND];
-        bool in_i = false;
+        const bool in_i = q < npl;
         size_t offp = 0;
+        int cb[ND];          // box coordinates of this lane's pixel
+        {
+          const int pk = in_i ? plist[q] : 0;
+#pragma unroll
+          for (int a = 0; a < ND; ++a) cb[a] = (pk >> (10 * (ND - 1 - a))) & 1023;
+        }
         // Which neighbours can touch this tile at all?  Lane l tests the box of neighbour l
-        // (centre +- radius, a superset of its mask) against the index extent of the 64
-        // consecutive box pixels: one ballot gives the candidates (as in block_kernel.h).
+        // (centre +- radius, a superset of its mask) against the index extent of the 64 list
+        // pixels (box order: the slowest axis runs from the first lane's to the last lane's
+        // value; an axis below one that changes spans its whole range): one ballot gives the
+        // candidates (as in block_kernel.h).
         unsigned long long cand;
         {
-          const int q0 = base, q1 = base + WAVE - 1 < npx ? base + WAVE - 1 : npx - 1;
+          const int last = (base + WAVE - 1 < npl ? WAVE - 1 : npl - 1 - base);
           int lo_i[ND], hi_i[ND];
-          int t0 = q0, t1 = q1;
           bool same = true;   // all slower axes equal so far
-          int c0[ND], c1[ND];
-#pragma unroll
-          for (int a = ND - 1; a >= 0; --a) {
-            c0[a] = t0 % bsz[a]; t0 /= bsz[a];
-            c1[a] = t1 % bsz[a]; t1 /= bsz[a];
-          }
 #pragma unroll
           for (int a = 0; a < ND; ++a) {
-            lo_i[a] = blo[a] + (same ? c0[a] : 0);
-            hi_i[a] = blo[a] + (same ? c1[a] : bsz[a] - 1);
-            same = same && c0[a] == c1[a];
+            const int c0 = __builtin_amdgcn_readfirstlane(cb[a]);
+            const int c1 = __builtin_amdgcn_readlane(cb[a], last);
+            lo_i[a] = blo[a] + (same ? c0 : 0);
+            hi_i[a] = blo[a] + (same ? c1 : bsz[a] - 1);
+            same = same && c0 == c1;
           }
           bool hit = lane < cnt;
 #pragma unroll
@@ -312,23 +324,13 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
             hit = hit && ((double)hi_i[a] >= nrel[a] - (double)radius[a]) && ((double)lo_i[a] <= nrel[a] + (double)radius[a]);
           cand = __ballot(hit);
         }
-        if (q < npx) {
-          int t = q;
 #pragma unroll
-          for (int a = ND - 1; a >= 0; --a) {
-            const int w = bsz[a];
-            const int c2 = t % w;
-            t /= w;
-            idx[a] = blo[a] + c2;
-          }
-          in_i = in_mask<ND>(idx, rel_i, inv_r2, radius);
+        for (int a = 0; a < ND; ++a) idx[a] = in_i ? blo[a] + cb[a] : 0;
+        if (in_i) {
           if (ND == 3)
             offp = ((size_t)(idx[0] + origin[0]) * fshape[1] + (idx[1] + origin[1])) * fshape[ND - 1] + (idx[ND - 1] + origin[ND - 1]);
           else
             offp = (size_t)(idx[0] + origin[0]) * fshape[ND - 1] + (idx[ND - 1] + origin[ND - 1]);
-        } else {
-#pragma unroll
-          for (int a = 0; a < ND; ++a) idx[a] = 0;
         }
 #pragma unroll
         for (int c2 = 0; c2 < 16; ++c2) row[c2] = 0.;
@@ -918,6 +920,46 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
           if (nbidx[(size_t)j * LARGE_MAXNB + s3] == i) r = s3;
         rev[(size_t)i * LARGE_MAXNB + s2] = r;
       }
+    }
+    // the mask pixels of every feature in this round's window, compacted: box coordinates in box
+    // order, 10 bits per axis (one wavefront per feature; 41 cheap tiles for a 9 x 17 x 17 box,
+    // once per round against ~25 passes over them)
+    for (int i = wave; i < n; i += LW) {
+      int blo[ND], bsz[ND], npx = 1;
+      double rel_i[ND];
+#pragma unroll
+      for (int a = 0; a < ND; ++a) {
+        rel_i[a] = mco[i * 3 + a] - (double)origin[a];
+        int l = (int)ceil(rel_i[a] - (double)radius[a]), u = (int)floor(rel_i[a] + (double)radius[a]);
+        l = l < 0 ? 0 : l;
+        u = u > wshape[a] - 1 ? wshape[a] - 1 : u;
+        blo[a] = l;
+        bsz[a] = u >= l ? u - l + 1 : 0;
+        npx *= bsz[a];
+      }
+      int* plist = pix_list + (size_t)i * W.cap;
+      int filled = 0;
+      for (int base = 0; base < npx; base += WAVE) {
+        const int q = base + lane;
+        bool in_i = false;
+        int pk = 0;
+        if (q < npx) {
+          int idx[ND], t = q;
+#pragma unroll
+          for (int a = ND - 1; a >= 0; --a) {
+            const int w = bsz[a];
+            const int c2 = t % w;
+            t /= w;
+            idx[a] = blo[a] + c2;
+            pk |= c2 << (10 * (ND - 1 - a));
+          }
+          in_i = in_mask<ND>(idx, rel_i, inv_r2, radius);
+        }
+        const unsigned long long bal = __ballot(in_i);
+        if (in_i) plist[filled + __popcll(bal & ((1ull << lane) - 1ull))] = pk;
+        filled += __popcll(bal);
+      }
+      if (lane == 0) pix_cnt[i] = filled;
     }
     // trial = clipped start vector
     bool infeasible = false;
