@@ -92,7 +92,9 @@ __host__ __device__ inline LargeWs large_ws(int n, int npf, int ns, long long ca
   // the mask pixels of every feature, compacted (int32: box coordinates, 10 bits per axis), rebuilt
   // every re-window round: [n] counts, then n lists of `cap` entries
   W.cap = (cap + 63) & ~63LL;
-  W.o_pix = o;  o += (W.nvp_i + nn * W.cap + 1) / 2 + 8;
+  // ... and, per feature, the pixels it shares with each neighbour j > i (a pool of `cap` entries
+  // per feature, [n][LARGE_MAXNB] offsets and counts; a pair that does not fit: count -1)
+  W.o_pix = o;  o += (W.nvp_i + 2 * nn * W.cap + 2 * nn * LARGE_MAXNB + 1) / 2 + 8;
   o = (o + 15) & ~15LL;
   W.o_sync = o; o += 64;                         // leader / helper words (large_kernel.h: LSY_*), zero at plan creation
   W.total = (o + 31) & ~31LL;

@@ -164,6 +164,9 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
   unsigned long long* sy = (unsigned long long*)(ws + W.o_sync);   // leader / helper words (LSY_*)
   int* pix_cnt = (int*)(ws + W.o_pix);         // mask pixels of feature i: count, then the list
   int* pix_list = pix_cnt + W.nvp_i;
+  int* pair_pool = pix_list + (size_t)n * W.cap;   // pixels shared with the neighbours j > i
+  int* pair_off = pair_pool + (size_t)n * W.cap;
+  int* pair_cnt = pair_off + (size_t)n * LARGE_MAXNB;
   // aggregates of the preconditioner: strongly coupled features share one diagonal block
   double* pre2 = ws + W.o_pre2;
   int* agg_of = (int*)(ws + W.o_agg);          // multi-feature aggregate of feature i, -1: on its own
@@ -486,21 +489,33 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
           np2 *= psz[a];
         }
         acc = v4d{0., 0., 0., 0.};
+        // the pixels in both masks: from the pair's list of this round (every lane at work), or,
+        // where that did not fit its pool, by walking the intersection of the two boxes
+        const int pc = pair_cnt[(size_t)i * LARGE_MAXNB + s2];
+        const int* ppl = pair_pool + (size_t)i * W.cap + pair_off[(size_t)i * LARGE_MAXNB + s2];
+        if (pc >= 0) np2 = pc;
         for (int base = 0; base < np2; base += WAVE) {
           const int q = base + lane;
           bool both = false;
           int idx[ND];
           size_t offp = 0;
           if (q < np2) {
-            int t = q;
+            if (pc >= 0) {
+              const int pk = ppl[q];
 #pragma unroll
-            for (int a = ND - 1; a >= 0; --a) {
-              const int w = psz[a];
-              const int c2 = t % w;
-              t /= w;
-              idx[a] = plo[a] + c2;
+              for (int a = 0; a < ND; ++a) idx[a] = blo[a] + ((pk >> (10 * (ND - 1 - a))) & 1023);
+              both = true;
+            } else {
+              int t = q;
+#pragma unroll
+              for (int a = ND - 1; a >= 0; --a) {
+                const int w = psz[a];
+                const int c2 = t % w;
+                t /= w;
+                idx[a] = plo[a] + c2;
+              }
+              both = in_mask<ND>(idx, rel_i, inv_r2, radius) && in_mask<ND>(idx, rel_j, inv_r2, radius);
             }
-            both = in_mask<ND>(idx, rel_i, inv_r2, radius) && in_mask<ND>(idx, rel_j, inv_r2, radius);
             if (ND == 3)
               offp = ((size_t)(idx[0] + origin[0]) * fshape[1] + (idx[1] + origin[1])) * fshape[ND - 1] + (idx[ND - 1] + origin[ND - 1]);
             else
@@ -960,7 +975,42 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         filled += __popcll(bal);
       }
       if (lane == 0) pix_cnt[i] = filled;
+      // ... and the pixels it shares with every neighbour j > i (out of its own list)
+      {
+        const int cnt = nbcnt[i];
+        int* pool = pair_pool + (size_t)i * W.cap;
+        int used = 0;
+        for (int s2 = 0; s2 < cnt; ++s2) {
+          const int j = nbidx[(size_t)i * LARGE_MAXNB + s2];
+          int got = 0;
+          if (j > i) {
+            double rel_j[ND];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) rel_j[a] = mco[j * 3 + a] - (double)origin[a];
+            for (int base = 0; base < filled && got >= 0; base += WAVE) {
+              const int q = base + lane;
+              bool both = false;
+              int pk = 0;
+              if (q < filled) {
+                pk = plist[q];
+                int idx[ND];
+#pragma unroll
+                for (int a = 0; a < ND; ++a) idx[a] = blo[a] + ((pk >> (10 * (ND - 1 - a))) & 1023);
+                both = in_mask<ND>(idx, rel_j, inv_r2, radius);
+              }
+              const unsigned long long bal = __ballot(both);
+              const int nb2 = __popcll(bal);
+              if (used + got + nb2 > (int)W.cap) { got = -1; break; }   // (the pool is full: the pass walks the box)
+              if (both) pool[used + got + __popcll(bal & ((1ull << lane) - 1ull))] = pk;
+              got += nb2;
+            }
+          }
+          if (lane == 0) { pair_off[(size_t)i * LARGE_MAXNB + s2] = used; pair_cnt[(size_t)i * LARGE_MAXNB + s2] = got; }
+          used += got > 0 ? got : 0;
+        }
+      }
     }
+    __syncthreads();
     // trial = clipped start vector
     bool infeasible = false;
     for (int i = tid; i < nv; i += LT) {
