@@ -80,7 +80,7 @@ __device__ __forceinline__ bool wg_any(bool x, double* red, int lane, int wave) 
 // passes, [3] ticks (100 MHz) in matrix-vector products, [4] in pixel passes, [5] in solves,
 // [6] / [7] wave 0 of the leader in feature tiles / pair blocks
 #ifdef CTR_STAMPS
-__device__ unsigned long long g_large_dbg[24];   // [8..]: solves and CG iterations by (model, outcome), see below
+__device__ unsigned long long g_large_dbg[32];   // [8..]: solves and CG iterations by (model, outcome), see below
 #define LDBG_ADD(slot, val) atomicAdd(&g_large_dbg[slot], (unsigned long long)(val))
 #define LDBG_NOW() __builtin_amdgcn_s_memrealtime()
 #define LDBG_CYC() __builtin_amdgcn_s_memtime()
@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
             todo &= todo - 1ull;
           }
           const unsigned long long tc_c = LDBG_CYC();
-          if (tid == 0 && !helper) { LDBG_ADD(20, tc_b - tc_a); LDBG_ADD(21, tc_c - tc_b); }
+          if (tid == 0 && !helper) { LDBG_ADD(24, tc_b - tc_a); LDBG_ADD(25, tc_c - tc_b); }
           (void)tc_a; (void)tc_b; (void)tc_c;
           Pown += (in_i && owner) ? 1 : 0;
           if (in_i && res == res) {   // nansum (fitfunc.py:449,483): a NaN pixel counts in P only
@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
           }
         }
         wsync();
-        if (tid == 0 && !helper) { LDBG_ADD(22, LDBG_CYC() - tc_d); LDBG_ADD(23, 1); }
+        if (tid == 0 && !helper) { LDBG_ADD(26, LDBG_CYC() - tc_d); LDBG_ADD(27, 1); }
         (void)tc_d;
       }
       // D layout: col = lane & 15, row = (lane >> 4) + 4 * reg

@@ -21,7 +21,7 @@ n_per = np.diff(b.feat_offset)
 print('stacks %d features %d clusters %d largest %s: %.3f s (%.0f features/s)' % (
     stacks, len(f0), b.n_clusters, np.sort(n_per)[-3:], dt, len(f0) / dt))
 import ctypes
-dbg = (ctypes.c_ulonglong * 24)()
+dbg = (ctypes.c_ulonglong * 32)()
 if hasattr(eng._lib, 'ctr_debug_large_counters') and eng._lib.ctr_debug_large_counters(dbg, 1) == 0:
     print('large path (both runs): solves %d, CG iterations %d (%.1f per solve), pixel passes %d' % (
         dbg[0], dbg[1], dbg[1] / max(dbg[0], 1), dbg[2]))
@@ -30,9 +30,9 @@ if hasattr(eng._lib, 'ctr_debug_large_counters') and eng._lib.ctr_debug_large_co
     for kq, name in enumerate(('exact Hessian, converged', 'exact Hessian, not positive definite', 'J^T J, converged', 'J^T J, failed')):
         ns, ni, ncap = dbg[8 + 4 * kq], dbg[9 + 4 * kq], dbg[10 + 4 * kq]
         print('  %-38s %6d solves, %8d CG iterations (%.1f per solve), %d at the iteration cap' % (name, ns, ni, ni / max(ns, 1), ncap))
-if dbg[23]:
+if dbg[27]:
     print('  per feature tile of the leader\'s wave 0 (%d tiles; shader-clock ticks): box test, index, mask, pixel %.0f; covering features %.0f; rows -> LDS, 16 MFMA %.0f' % (
-        dbg[23], dbg[20] / dbg[23], dbg[21] / dbg[23], dbg[22] / dbg[23]))
+        dbg[27], dbg[24] / dbg[27], dbg[25] / dbg[27], dbg[26] / dbg[27]))
 print('status counts', np.bincount(b.status), 'rounds', b.n_rounds[:8], 'iters', b.n_iter[:8])
 out = np.empty_like(b.params_out); out[prep.order] = b.params_out
 ok = np.empty(len(out), bool); ok[prep.order] = np.repeat(b.status == 0, n_per)
