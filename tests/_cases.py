@@ -102,7 +102,11 @@ def refine_leastsq_sharded(*args, **kwargs):
 def is_solver_specific(name):
     """Fixtures whose outcome depends on the minimiser itself: constrained fits that one of the
     reference's two runs (defaults = A, converged = B) fails, or that end in poor minima."""
-    return name.startswith('hard_cons_') or name.startswith('tetramer2d_') or name == 'ring_2d_a_thickness'
+    # big_cluster_close_pairs: one cluster of 80 features with start positions 0.4-0.7 px apart (the
+    # large-cluster path; the reference's DEFAULT run fails on it at its 100 iterations, its converged
+    # run ends at cost 0.015501, the engine at 0.015488: compared by cost)
+    return name.startswith('hard_cons_') or name.startswith('tetramer2d_') or \
+        name in ('ring_2d_a_thickness', 'big_cluster_close_pairs')
 
 
 # (fixture, cluster id): the reference fits it and the engine's minimiser returns NaN.  EMPTY since

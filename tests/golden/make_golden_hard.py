@@ -110,7 +110,34 @@ def big_clusters():
                  dict(diameter=[9, 17, 17]), do_intermediates=False)
 
 
+def big_cluster_close_pairs():
+    """A cluster of the large-cluster path (80 features, 241 variables) in which some start
+    positions are 0.4-0.7 px apart, as in BASELINE cfg 3 at its stated density: features that
+    close leave nearly dependent columns (the case the preconditioner's aggregates are for,
+    DESIGN.md 4.5).  What does the REFERENCE do on such a cluster?  It fits it (both runs)."""
+    import numpy as np
+    from clustertracking_amd import artificial
+    rng = np.random.RandomState(8)
+    size, ny, nx, sp = 3., 8, 9, 11.
+    truth = np.array([[sp * (1 + gy), sp * (1 + gx)] for gy in range(ny) for gx in range(nx)]) \
+        + rng.uniform(-1.5, 1.5, (ny * nx, 2))
+    # eight more features right next to an existing one (0.4-0.7 px apart, 0.13-0.23 sizes)
+    partners = rng.choice(len(truth), 8, replace=False)
+    ang = rng.uniform(0, 2 * np.pi, 8)
+    rad = rng.uniform(0.4, 0.7, 8)
+    truth = np.concatenate([truth, truth[partners] + np.stack([rad * np.sin(ang), rad * np.cos(ang)], 1)])
+    im = np.zeros((int(sp * (ny + 1)), int(sp * (nx + 1))), np.uint8)
+    for p in truth:
+        artificial.draw_gaussian(im, p, size, 100)
+    im = artificial.add_poisson_noise(im, 10, rng)
+    p0 = truth + rng.uniform(-0.15, 0.15, truth.shape)
+    mg.save_case('big_cluster_close_pairs', mg.table(p0, size, 90., 5., 2, True), im[None],
+                 dict(diameter=13), do_intermediates=False)
+
+
 def main(only=None):
+    if only is None or 'big_cluster_close_pairs' in only:
+        big_cluster_close_pairs()
     if only is None or 'tetramer2d' in only:
         tetramer2d()
     if only is None or 'big_clusters' in only:

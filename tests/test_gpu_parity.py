@@ -55,7 +55,7 @@ def test_golden_case_engine_vs_oracle_and_reference(engine, oracle, name):
     A, B = case.ref('A'), case.ref('B')
     pc = case.pos_columns
     if _cases.is_solver_specific(name):
-        assert _cases.check_solver_specific(name, res, A, B, pc) >= 2
+        assert _cases.check_solver_specific(name, res, A, B, pc) >= min(2, res['cluster'].nunique())
         return
     assert_equal(np.isnan(res['cost'].values), np.isnan(B['cost'].values))
     ok = ~np.isnan(res['cost'].values)
