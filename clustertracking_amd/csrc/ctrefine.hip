@@ -792,10 +792,11 @@ int ctr_ipc_open(ctr_handle* h, const unsigned char* handle, void** dev_ptr) {
   void* p = nullptr;
   const hipError_t e = hipIpcOpenMemHandle(&p, ih, hipIpcMemLazyEnablePeerAccess);
   if (e != hipSuccess) return fail(h, CTR_ERR_DEVICE, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
-  // cross-check where the runtime can tell: the mapped pointer must belong to that owner
+  // cross-check where the runtime can tell: the mapped pointer belongs to that owner (or is
+  // reported under the device that mapped it -- runtimes differ), never to a third device
   hipPointerAttribute_t attr;
   if (hipPointerGetAttributes(&attr, p) == hipSuccess) {
-    if (attr.device != owner) {
+    if (attr.device != owner && attr.device != h->device) {
       (void)hipIpcCloseMemHandle(p);
       return fail(h, CTR_ERR_DEVICE, "the mapped block does not belong to the device named in its handle");
     }
