@@ -7,11 +7,11 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 IPC_HANDLE_BYTES = 128
 MAX_NDIM = 3
 MAX_NOISE_SIZE = 4.0
-MAX_PARAMS = 9
+MAX_PARAMS = 12
 MAX_VARS = 127
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NOMEM = range(5)
@@ -22,6 +22,18 @@ DTYPE_CODES = {np.dtype(np.uint8): 0, np.dtype(np.uint16): 1, np.dtype(np.int16)
 FIT_GAUSS, FIT_RING, FIT_DISC, FIT_INV_SERIES = 0, 1, 2, 3
 FIT_CODES = {'gauss': FIT_GAUSS, 'ring': FIT_RING, 'disc': FIT_DISC}
 FIT_EXTRAS = {FIT_GAUSS: 0, FIT_RING: 1, FIT_DISC: 1}   # profile parameters after the sizes
+
+
+def fit_code(fit_function):
+    """(CTR_FIT_* code, number of profile parameters) of a fit function name; ``'inv_series_<N>'``
+    has N + 1 of them (fitfunc.py:334-343)."""
+    if fit_function in FIT_CODES:
+        code = FIT_CODES[fit_function]
+        return code, FIT_EXTRAS[code]
+    head, _, order = str(fit_function).rpartition('_')
+    if head == 'inv_series' and order.isdigit():
+        return FIT_INV_SERIES, int(order) + 1
+    raise ValueError("fit_function must be one of %s or 'inv_series_<N>'" % sorted(FIT_CODES))
 MODE_CONST, MODE_VAR, MODE_GLOBAL, MODE_CLUSTER = 0, 1, 2, 3
 CONS_NONE, CONS_DIMER, CONS_TRIMER, CONS_TETRAMER = 0, 1, 2, 3
 CONS_CODES = {None: 0, 'dimer': 1, 'trimer': 2, 'tetramer': 3}
@@ -92,10 +104,11 @@ def make_problem(ndim, isotropic, modes, radius, constraint=None, max_iter=10,
     p = Problem()
     p.ndim = int(ndim)
     p.isotropic = int(bool(isotropic))
-    if fit_function not in FIT_CODES:
-        raise ValueError("fit_function must be one of %s" % sorted(FIT_CODES))
-    p.fit_function = FIT_CODES[fit_function]
-    p.n_params = 2 + ndim + (1 if isotropic else ndim) + FIT_EXTRAS[p.fit_function]
+    p.fit_function, n_extra = fit_code(fit_function)
+    p.n_params = 2 + ndim + (1 if isotropic else ndim) + n_extra
+    if p.n_params > MAX_PARAMS:
+        raise NotImplementedError("%s in %dD%s: %d parameter columns, the engine takes %d"
+                                  % (fit_function, ndim, '' if isotropic else ' anisotropic', p.n_params, MAX_PARAMS))
     if len(modes) != p.n_params:
         raise ValueError("modes must have %d entries" % p.n_params)
     for i, m in enumerate(modes):

@@ -61,14 +61,25 @@ def feat_disc(r, ndim, disc_size):
     return result
 
 
+def feat_inv_series(r, ndim, p):
+    """The profile the ``'inv_series_<N>'`` fit function evaluates (reference fitfunc.py:148-154):
+    ``p[0] / polyval([1, p[1], ..., p[N]], r**2)``.  (The reference's artificial.py has no drawing
+    function for it; this one serves the fixtures of that fit function.)"""
+    c = np.array(p, dtype=np.float64)
+    c[0] = 1.
+    return p[0] / np.polyval(c, r ** 2)
+
+
 def draw_feature(image, position, size, max_value, feat_func='gauss', **kwargs):
     """Add one radially symmetric feature in place: the reference's ``draw_feature``
     (artificial.py:81-141; patch of 8 x size per axis, ``r = sqrt(sum(((idx - c)/size)^2))``, the
     spot truncated to the image dtype and added with integer wrap-around) for ``feat_func`` =
-    'gauss', 'ring' (``thickness=``) or 'disc' (``disc_size=``)."""
+    'gauss', 'ring' (``thickness=``), 'disc' (``disc_size=``), 'inv_series' (``p=``) or a callable
+    ``feat_func(r, ndim=..., **kwargs)`` as there."""
     if feat_func == 'gauss':
         return draw_gaussian(image, position, size, max_value)
-    func = dict(ring=feat_ring, disc=feat_disc)[feat_func]
+    func = feat_func if callable(feat_func) else \
+        dict(ring=feat_ring, disc=feat_disc, inv_series=feat_inv_series)[feat_func]
     ndim = image.ndim
     size = _as_tuple(size, ndim)
     sl = []

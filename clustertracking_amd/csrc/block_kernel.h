@@ -253,8 +253,9 @@ __device__ unsigned long long g_stamps[16];
 // (it costs the unconstrained fits registers otherwise: 700 B of scratch per lane, measured).
 // LP: the instantiation for problems with a lowpass of the window (ctr_problem.noise_size): every
 // pixel value is the filtered one, computed from the raw frame where it is needed.
-// FIT: the radial profile (CTR_FIT_GAUSS / RING / DISC, device_common.h:profile_dev); ring and disc
-// carry one more parameter column (thickness / disc_size) and iterate with the Gauss-Newton model.
+// FIT: the radial profile (CTR_FIT_GAUSS / RING / DISC / INV_SERIES; device_common.h:profile_dev,
+// profile_inv_dev); ring and disc carry one more parameter column (thickness / disc_size),
+// inv_series_<N> N + 1 (signal_mult, param_a, ...); all three iterate with the Gauss-Newton model.
 // Minimum wavefronts per SIMD asked of the compiler (the register budget) for the instantiations
 // of the throughput scheduling (2D, fewest wavefronts per cluster: W = 2 for NT <= 2, 1 above).
 // NT = 1 (3-4 features): 3 -- 168 VGPRs + 272 B of scratch instead of 231 + 100 at 2 per SIMD:
@@ -281,9 +282,16 @@ refine_block_kernel(const KArgs k) {
   unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
 #endif
   using SM = SmemB<NT, W, CONS>;
-  constexpr int NX = FIT != CTR_FIT_GAUSS ? 1 : 0;    // profile parameters after the sizes
-  constexpr int NP = 2 + ND + (ISO ? 1 : ND) + NX;
+  // profile parameters after the sizes: one for ring / disc; inv_series_<N> has N + 1 of them, known
+  // at run time: NP is then the problem's n_params, NPC (the bound of the unrolled loops over the
+  // parameter columns) its maximum; columns beyond n_params are constants to the layout
+  constexpr int NX = FIT == CTR_FIT_INV_SERIES ? INV_NX : (FIT != CTR_FIT_GAUSS ? 1 : 0);
   constexpr int NSZ = ISO ? 1 : ND;
+  constexpr int NPC_ = 2 + ND + NSZ + NX;
+  constexpr int NPC = NPC_ < CTR_MAX_PARAMS ? NPC_ : CTR_MAX_PARAMS;
+  const int NP = FIT == CTR_FIT_INV_SERIES ? k.prob.n_params : NPC;
+  const int nx_inv = NP - (2 + ND + NSZ);
+  constexpr bool SAFE_R2 = FIT == CTR_FIT_RING || FIT == CTR_FIT_DISC;   // r2_*_safe (fitfunc.py:396-411)
   constexpr int LDC = SM::NVC;
   extern __shared__ double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -340,7 +348,7 @@ refine_block_kernel(const KArgs k) {
   // [4..6] 1/size^2 [7..9] 2/size^2 [10..12] -2/size^3   (wave 0)
   bool size_is_var = false;
 #pragma unroll
-  for (int kk = 2 + ND; kk < NP; ++kk) size_is_var = size_is_var || L.slot[kk] >= 0;
+  for (int kk = 2 + ND; kk < NPC; ++kk) size_is_var = size_is_var || L.slot[kk] >= 0;
   // constrained fits with other than the default modes: the second-order part in ALL variables
   // (second_order_pass after every accepted step) instead of the (signal, position) part that
   // the pixel pass sums (same rule: oracle solve(), fullq)
@@ -353,7 +361,7 @@ refine_block_kernel(const KArgs k) {
     for (int i = lane; i < n; i += WAVE) {
       double* f = fpar + i * FP;
       f[0] = par(vv, i, 1);
-      if (NX) f[13] = par(vv, i, NP - 1);   // the profile parameter
+      if (SAFE_R2) f[13] = par(vv, i, NPC - 1);   // the profile parameter (ring, disc)
 #pragma unroll
       for (int a = 0; a < ND; ++a) {
         f[1 + a] = par(vv, i, 2 + a);
@@ -728,7 +736,7 @@ refine_block_kernel(const KArgs k) {
     const double* low = k.low + (size_t)f0 * NP;
     const double* high = k.high + (size_t)f0 * NP;
 #pragma unroll
-    for (int kk = 0; kk < NP; ++kk) {
+    for (int kk = 0; kk < NPC; ++kk) {
       if (L.slot[kk] < 0) continue;
       if (L.per_feat[kk]) {
         for (int i = tid; i < n; i += WAVE * W) {
@@ -903,9 +911,9 @@ refine_block_kernel(const KArgs k) {
         while (todo != 0ull) {
           const int i = __builtin_ctzll(todo);
           todo &= todo - 1ull;
-          double d[1 + ND + NSZ + NX];
+          double d[NPC - 1];
 #pragma unroll
-          for (int t = 0; t < 1 + ND + NSZ + NX; ++t) d[t] = 0.;
+          for (int t = 0; t < NPC - 1; ++t) d[t] = 0.;
           bool in = false;
           if (valid && ((cand >> i) & 1ull)) {
             double rel[ND];
@@ -930,6 +938,16 @@ refine_block_kernel(const KArgs k) {
             if constexpr (FIT == CTR_FIT_GAUSS) {
               gv = exp(-0.5 * ND * r2);  // fitfunc.py:112-118
               sdg = sig * (0.5 * ND) * gv;  // -signal * dg/dr2
+            } else if constexpr (FIT == CTR_FIT_INV_SERIES) {
+              // the profile parameters of the trial vector (constants or variables: par())
+              double ex[INV_NX], dge[INV_NX], dg;
+#pragma unroll
+              for (int t = 0; t < INV_NX; ++t) ex[t] = t < nx_inv ? par(vt, i, 2 + ND + NSZ + t) : 0.;
+              profile_inv_dev(nx_inv, r2, ex, gv, dg, dge);
+              sdg = -sig * dg;
+#pragma unroll
+              for (int t = 0; t < INV_NX; ++t)
+                if (1 + ND + NSZ + t < NPC - 1) d[1 + ND + NSZ + t] = -sig * dge[t];   // fitfunc.py:480-481
             } else {
               double qraw = 0., dg, dge;
 #pragma unroll
@@ -956,14 +974,14 @@ refine_block_kernel(const KArgs k) {
           // branch-free scatter: columns of constant / shared parameters go to the pad
           // column of the row (index 16*NT, never read by the MFMA)
 #pragma unroll
-          for (int kk = 1; kk < NP; ++kk) {
+          for (int kk = 1; kk < NPC; ++kk) {
             row[pf_base[kk] + pf_step[kk] * i] = d[kk - 1];
             shared[kk] += d[kk - 1];
           }
         }
         const bool good = any && (res == res);  // nansum (fitfunc.py:449,483)
 #pragma unroll
-        for (int kk = 1; kk < NP; ++kk)
+        for (int kk = 1; kk < NPC; ++kk)
           if (L.slot[kk] >= 0 && !L.per_feat[kk]) row[1 + L.slot[kk]] = good ? shared[kk] : 0.;
         if (L.slot[0] >= 0) row[1 + L.slot[0]] = good ? -1. : 0.;
         row[0] = good ? res : 0.;
@@ -1643,7 +1661,7 @@ refine_block_kernel(const KArgs k) {
         for (int i = lane; i < n; i += WAVE) {
           double d2 = 0.;
 #pragma unroll
-          for (int kk = 0; kk < NP; ++kk) {
+          for (int kk = 0; kk < NPC; ++kk) {
             const int b = L.vidx(kk, i);
             if (b >= 0) cur[i * CTR_MAX_PARAMS + kk] = v[b];
           }

@@ -108,10 +108,10 @@ struct ctr_handle {
   small_fn small_bulk2[2][2];     // pairs with 16 lanes per cluster (the bulk of a pairs bin)
   KernelInfo lp[2][2][MAXNT];     // block kernel with the lowpass of the window: [ndim-2][iso][nt-1]
   KernelInfo lp_cons[2][2][2];    // ... for constrained clusters, nt = 1, 2
-  KernelInfo fit[2][2][2][MAXNT]; // ring / disc profiles: [fit-1][ndim-2][iso][nt-1]
-  KernelInfo fit_cons[2][2][2][2];
-  bool fit_attr[2][2][2][MAXNT] = {};
-  bool fit_cons_attr[2][2][2][2] = {};
+  KernelInfo fit[3][2][2][MAXNT]; // ring / disc / inv_series profiles: [fit-1][ndim-2][iso][nt-1]
+  KernelInfo fit_cons[3][2][2][2];
+  bool fit_attr[3][2][2][MAXNT] = {};
+  bool fit_cons_attr[3][2][2][2] = {};
   bool lp_attr[2][2][MAXNT] = {};
   bool lp_cons_attr[2][2][2] = {};
   KernelInfo large[2][2][2];      // refine_large_kernel<ndim, iso, lowpass>
@@ -140,13 +140,17 @@ int fail(ctr_handle* h, int code, const std::string& msg) {
 int validate(const ctr_problem* p, std::string& msg) {
   if (!p) { msg = "null problem"; return CTR_ERR_INVALID; }
   if (p->ndim != 2 && p->ndim != 3) { msg = "ndim must be 2 or 3"; return CTR_ERR_INVALID; }
-  if (p->fit_function != CTR_FIT_GAUSS && p->fit_function != CTR_FIT_RING && p->fit_function != CTR_FIT_DISC) {
-    msg = "fit function not implemented (gauss, ring and disc are)";
-    return (p->fit_function >= 0 && p->fit_function <= CTR_FIT_INV_SERIES) ? CTR_ERR_UNSUPPORTED : CTR_ERR_INVALID;
-  }
+  if (p->fit_function < CTR_FIT_GAUSS || p->fit_function > CTR_FIT_INV_SERIES) { msg = "unknown fit function"; return CTR_ERR_INVALID; }
   const bool other_profile = p->fit_function != CTR_FIT_GAUSS;
-  // ring: 'thickness', disc: 'disc_size' -- one more column after the sizes (fitfunc.py:195-204)
-  const int np = 2 + p->ndim + (p->isotropic ? 1 : p->ndim) + (other_profile ? 1 : 0);
+  // ring: 'thickness', disc: 'disc_size' -- one more column after the sizes (fitfunc.py:195-204);
+  // inv_series_<N>: 'signal_mult', 'param_a', ... N + 1 columns (fitfunc.py:334-343)
+  const int base = 2 + p->ndim + (p->isotropic ? 1 : p->ndim);
+  int np = base + (other_profile ? 1 : 0);
+  if (p->fit_function == CTR_FIT_INV_SERIES) {
+    if (p->n_params < base + 1) { msg = "inv_series needs at least the column 'signal_mult'"; return CTR_ERR_INVALID; }
+    if (p->n_params > CTR_MAX_PARAMS) { msg = "inv_series: more than CTR_MAX_PARAMS parameter columns"; return CTR_ERR_UNSUPPORTED; }
+    np = p->n_params;
+  }
   if (p->n_params != np) { msg = "n_params does not match ndim/isotropic"; return CTR_ERR_INVALID; }
   for (int k = 0; k < np; ++k) {
     const int m = p->modes[k];
@@ -171,7 +175,7 @@ int validate(const ctr_problem* p, std::string& msg) {
   if (other_profile) {
     bool lp = (p->flags & CTR_FLAG_WINDOW_FILTER) != 0;
     for (int a = 0; a < p->ndim; ++a) lp = lp || p->noise_size[a] > 0.;
-    if (lp) { msg = "noise_size together with the ring / disc profiles is not implemented"; return CTR_ERR_UNSUPPORTED; }
+    if (lp) { msg = "noise_size together with a profile other than gauss is not implemented"; return CTR_ERR_UNSUPPORTED; }
   }
   return CTR_OK;
 }
@@ -320,6 +324,8 @@ int ctr_create(ctr_handle** out, int device) {
           h->fit[fi][di][ii][nt - 1] = di == 0 ? ctr_block_kernel_fit2d(ii, nt, 0, fi + 1) : ctr_block_kernel_fit3d(ii, nt, 0, fi + 1);
           if (nt <= 2) h->fit_cons[fi][di][ii][nt - 1] = di == 0 ? ctr_block_kernel_fit2d(ii, nt, 1, fi + 1) : ctr_block_kernel_fit3d(ii, nt, 1, fi + 1);
         }
+        h->fit[2][di][ii][nt - 1] = ctr_block_kernel_inv(2 + di, ii, nt, 0);
+        if (nt <= 2) h->fit_cons[2][di][ii][nt - 1] = ctr_block_kernel_inv(2 + di, ii, nt, 1);
         if (nt <= 2)
           for (int tp = 0; tp < 2; ++tp)
             h->cons[di][ii][tp][nt - 1] = di == 0 ? ctr_block_kernel_2d(ii, nt, tp, 1) : ctr_block_kernel_3d(ii, nt, tp, 1);
@@ -586,7 +592,7 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     // (2D only: a 3D window has thousands of pixels, more wavefronts per cluster pay there)
     const bool tp = (p.flags & CTR_FLAG_THROUGHPUT) != 0 && p.ndim == 2;
     const bool lpk = plan->lowpass;
-    const int fi = p.fit_function - 1;   // >= 0: ring / disc
+    const int fi = p.fit_function - 1;   // >= 0: ring / disc / inv_series
     kernel_fn fn = fi >= 0 ? h->fit[fi][di][ii][bin].fn : lpk ? h->lp[di][ii][bin].fn : (tp ? h->table_tp[di][ii][bin] : h->table[di][ii][bin]);
     const size_t bytes = fi >= 0 ? h->fit[fi][di][ii][bin].smem : lpk ? h->lp[di][ii][bin].smem : (tp ? h->smem_bytes_tp[di][ii][bin] : h->smem_bytes[di][ii][bin]);
     const int threads = fi >= 0 ? h->fit[fi][di][ii][bin].threads : lpk ? h->lp[di][ii][bin].threads : (tp ? h->block_threads_tp[di][ii][bin] : h->block_threads[di][ii][bin]);
@@ -607,7 +613,7 @@ int ctr_refine_batch_device(ctr_handle* h, const ctr_plan* plan, const ctr_batch
     const int64_t cnt = plan->bin_count[bin];
     if (cnt == 0) continue;
     const int tp = ((p.flags & CTR_FLAG_THROUGHPUT) != 0 && p.ndim == 2) ? 1 : 0;
-    const int fi = p.fit_function - 1;   // >= 0: ring / disc
+    const int fi = p.fit_function - 1;   // >= 0: ring / disc / inv_series
     const KernelInfo& ki = fi >= 0 ? h->fit_cons[fi][di][ii][cb] : plan->lowpass ? h->lp_cons[di][ii][cb] : h->cons[di][ii][tp][cb];
     bool& cattr = fi >= 0 ? h->fit_cons_attr[fi][di][ii][cb] : plan->lowpass ? h->lp_cons_attr[di][ii][cb] : h->cons_attr[di][ii][tp][cb];
     if (!cattr) {

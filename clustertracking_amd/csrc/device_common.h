@@ -157,6 +157,29 @@ __device__ __forceinline__ void profile_dev(double r2, double e, double& g, doub
   }
 }
 
+// inv_series_<N> (fitfunc.py:148-154): g = e[0] / y(r2), y = np.polyval([1, e[1], ..., e[N]], r2)
+// = r2^N + e[1] r2^(N-1) + ... + e[N] in Horner's order; nx = N + 1 profile parameters, at most
+// INV_NX.  The reference has no derivative of it (its SLSQP differentiates the objective
+// numerically); these are the analytic ones: dg/dr2 = -e[0] y'/y^2, dg/de[0] = 1/y,
+// dg/de[k] = -e[0] r2^(N-k) / y^2.  Same expressions as oracle/ctr_oracle.c:profile_inv.
+constexpr int INV_NX = 7;
+__device__ __forceinline__ void profile_inv_dev(int nx, double r2, const double* e, double& g, double& dg_dr2, double* dg_de) {
+  double y = 1., dy = 0.;
+#pragma unroll
+  for (int t = 1; t < INV_NX; ++t)
+    if (t < nx) { dy = dy * r2 + y; y = y * r2 + e[t]; }
+  const double inv = 1. / y, c = -e[0] * (inv * inv);
+  g = e[0] / y;
+  dg_dr2 = c * dy;
+  dg_de[0] = inv;
+  double pw = 1.;
+#pragma unroll
+  for (int t = INV_NX - 1; t >= 1; --t) {
+    dg_de[t] = 0.;
+    if (t < nx) { dg_de[t] = c * pw; pw *= r2; }
+  }
+}
+
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
 
 struct Layout {

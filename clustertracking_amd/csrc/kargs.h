@@ -112,6 +112,7 @@ KernelInfo ctr_block_kernel_lp(int ndim, int iso, int nt, int cons);
 // ring / disc profiles (FIT = CTR_FIT_RING / CTR_FIT_DISC); cons: nt = 1..3
 KernelInfo ctr_block_kernel_fit2d(int iso, int nt, int cons, int fit);
 KernelInfo ctr_block_kernel_fit3d(int iso, int nt, int cons, int fit);
+KernelInfo ctr_block_kernel_inv(int ndim, int iso, int nt, int cons);   // FIT = CTR_FIT_INV_SERIES
 // refine_small_kernel<ND, NF, ISO, SG>(KArgs, int* counter); nullptr if not instantiated
 const void* ctr_small_kernel(int ndim, int nf, int iso, int sg);
 KernelInfo ctr_large_kernel(int ndim, int iso, int lp);   // lp: with the lowpass of the window

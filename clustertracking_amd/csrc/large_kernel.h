@@ -1461,6 +1461,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         if (tid == 0) {
           const int kq = (nwt ? 0 : 2) + (cg_fail ? 1 : 0);
           LDBG_ADD(8 + 4 * kq, 1); LDBG_ADD(9 + 4 * kq, cg_it); LDBG_ADD(10 + 4 * kq, cg_it >= cg_max ? 1 : 0);
+          (void)kq;
         }
         (void)tc0; (void)cg_it;
         if (cg_fail) continue;

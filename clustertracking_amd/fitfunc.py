@@ -30,8 +30,9 @@ class FitFunctions(object):
     Column order of the per-feature parameter matrix (reference
     fitfunc.py:353-354): ``[background, signal, (z,) y, x, size | size_(z,)y,x]``.
     ``'ring'`` and ``'disc'`` add one profile parameter after the sizes (``thickness`` /
-    ``disc_size``, fitfunc.py:195-204); ``'inv_series_N'`` and custom functions are recognised
-    and rejected with a clear message.
+    ``disc_size``, fitfunc.py:195-204), ``'inv_series_<N>'`` N + 1 (``signal_mult``, ``param_a``,
+    ..., all 1 by default; fitfunc.py:148-154,334-343); custom (dict) functions are rejected with a
+    clear message.
     """
 
     def __init__(self, fit_function='gauss', ndim=2, isotropic=True,
@@ -40,21 +41,21 @@ class FitFunctions(object):
             raise NotImplementedError(
                 "custom (dict) fit functions need Python callbacks per "
                 "evaluation and are not supported by the MI355X engine")
-        if fit_function not in FIT_TEMPLATES:
-            base = fit_function.rsplit('_', 1)[0] if fit_function not in \
-                FIT_FUNCTION_CODES else fit_function
-            if base in FIT_FUNCTION_CODES:
-                raise NotImplementedError(
-                    "fit_function %r is reserved in the C-ABI but not implemented by the MI355X "
-                    "engine ('gauss', 'ring' and 'disc' are)" % fit_function)
-            raise ValueError("Unknown fit function {}".format(fit_function))
+        if fit_function in FIT_TEMPLATES:
+            tmpl = FIT_TEMPLATES[fit_function]
+        else:
+            # fitfunc.py:334-343: '<name>_<order>' = a template with generated parameter names
+            head, _, order = str(fit_function).rpartition('_')
+            if head != 'inv_series' or not order.isdigit():
+                raise ValueError("Unknown fit function {}".format(fit_function))
+            names = ['signal_mult'] + ['param_' + chr(i) for i in range(97, 97 + int(order))]
+            tmpl = dict(params=names, default={p: 1. for p in names}, continuous=True)
         self.fit_function = fit_function
         self.ndim = int(ndim)
         self.isotropic = bool(isotropic)
         self.pos_columns = default_pos_columns(ndim)
         self.size_columns = default_size_columns(ndim, isotropic)
         # reference fitfunc.py:195-204: the profile's own parameters and their defaults
-        tmpl = FIT_TEMPLATES[fit_function]
         self._params = list(tmpl['params'])
         self.default = dict(background=0., **tmpl['default'])
         self.continuous = tmpl['continuous']

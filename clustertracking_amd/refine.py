@@ -219,12 +219,13 @@ def refine_leastsq(f, reader, diameter, separation=None, fit_function='gauss',
       ``xtol``, ``ftol``, ``device``, ``cluster_labels`` ('reference': ids equal to
       the reference's, labelled on the host; 'device': same partition labelled on
       the GPU, canonical ids).
-    * ``fit_function``: ``'gauss'``, ``'ring'`` and ``'disc'`` (fitfunc.py:112-146, with the
-      profile parameter ``thickness`` / ``disc_size`` as a column like any other: constant by
-      default, ``param_val`` sets it); ``'inv_series_N'``, custom (dict) functions and the
-      ``param_mode`` value ``'global'`` raise ``NotImplementedError`` (there is no CPU fallback to
-      hand them to).  Ring and disc fits iterate with the Gauss-Newton model, have no
-      ``compute_error`` (NaN) and are limited to clusters of 64 features / 127 variables.
+    * ``fit_function``: ``'gauss'``, ``'ring'``, ``'disc'`` and ``'inv_series_<N>'`` (fitfunc.py:112-154,
+      with the profile parameters ``thickness`` / ``disc_size`` / ``signal_mult, param_a, ...`` as
+      columns like any other: constant by default, ``param_val`` sets them); custom (dict)
+      functions and the ``param_mode`` value ``'global'`` raise ``NotImplementedError`` (there is no
+      CPU fallback to hand them to).  Fits of the other profiles iterate with the Gauss-Newton
+      model, have no ``compute_error`` (NaN) and are limited to clusters of 64 features / 127
+      variables and to 12 parameter columns.
     * ``noise_size`` (the lowpass of every window, refine.py:37-40) up to sigma 4.
     * ``compute_error``: the ``'<param>_std'`` columns come from the exact second
       derivatives of the objective (the reference differentiates numerically with

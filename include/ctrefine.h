@@ -27,9 +27,10 @@
 extern "C" {
 #endif
 
-#define CTR_ABI_VERSION 6
+#define CTR_ABI_VERSION 7
 #define CTR_MAX_NDIM 3
-#define CTR_MAX_PARAMS 9 /* background, signal, <=3 positions, <=3 sizes, <=1 profile parameter */
+#define CTR_MAX_PARAMS 12 /* background, signal, <=3 positions, <=3 sizes, profile parameters (ring, disc: 1;
+                              inv_series_<N>: N + 1, as many as fit: N <= 6 in 2D isotropic, <= 3 in 3D anisotropic) */
 #define CTR_MAX_VARS 127 /* optimiser variables per cluster of the on-chip kernels; larger clusters
                             (or more than 64 features) take the large-cluster path: normal matrix
                             block-sparse in HBM, no limit on features or variables */
@@ -40,7 +41,7 @@ extern "C" {
 enum {
   CTR_OK = 0,
   CTR_ERR_INVALID = 1,     /* malformed descriptor (reference: ValueError / AssertionError, refine.py:256-262,283) */
-  CTR_ERR_UNSUPPORTED = 2, /* recognised but not implemented (mode 'global', non-gauss profile) */
+  CTR_ERR_UNSUPPORTED = 2, /* recognised but not implemented (mode 'global', a lowpass with a profile other than gauss) */
   CTR_ERR_DEVICE = 3,      /* HIP runtime failure, no MI355X visible, ... */
   CTR_ERR_NOMEM = 4
 };
@@ -55,8 +56,10 @@ enum {
   CTR_DTYPE_F64 = 5
 };
 
-/* radial profile (fitfunc.py:112-146,195-204): GAUSS, RING ('thickness' column) and DISC ('disc_size'
- * column) are implemented; INV_SERIES is reserved (CTR_ERR_UNSUPPORTED) */
+/* radial profile (fitfunc.py:112-154,195-204,334-343): GAUSS, RING ('thickness' column), DISC
+ * ('disc_size' column) and INV_SERIES: 'inv_series_<N>' = signal_mult / (r2^N + param_a r2^(N-1) + ... +
+ * param_<N>) (what fitfunc.py:148-154 evaluates: np.polyval with the leading coefficient set to 1),
+ * N + 1 columns 'signal_mult', 'param_a', ...; N = n_params - (2 + ndim + sizes) - 1 */
 enum { CTR_FIT_GAUSS = 0, CTR_FIT_RING = 1, CTR_FIT_DISC = 2, CTR_FIT_INV_SERIES = 3 };
 
 /* parameter modes (fitfunc.py:9-11); 2 ('global') is rejected: it couples all
@@ -105,7 +108,7 @@ typedef struct ctr_problem {
   int32_t n_params;                /* 2 + ndim + (isotropic ? 1 : ndim) + extras; column order
                                       [background, signal, (z,) y, x, size | size_(z,)y,x, extra]
                                       (fitfunc.py:353-354); extras: 0 for gauss, 1 for ring
-                                      ('thickness') and disc ('disc_size') */
+                                      ('thickness') and disc ('disc_size'), N + 1 for inv_series_<N> */
   int32_t modes[CTR_MAX_PARAMS];   /* CTR_MODE_* per column (fitfunc.py:394) */
   int32_t radius[CTR_MAX_NDIM];    /* mask radius per axis = diameter // 2 (refine.py:286) */
   int32_t constraint_kind;         /* CTR_CONS_* */
@@ -157,8 +160,8 @@ typedef struct ctr_batch {
                                   parameters, failed clusters and a Hessian that is not positive
                                   definite.  Every parameter mode (second derivatives w.r.t.
                                   signal, centres and sizes).  NaN for clusters of the
-                                  large-cluster path (> 64 features) and for the ring / disc
-                                  profiles (the second derivatives are the gaussian's). */
+                                  large-cluster path (> 64 features) and for the ring / disc /
+                                  inv_series profiles (the second derivatives are the gaussian's). */
   double* result_rows;         /* [N, n_params + 1] or NULL: params_out and, last column, the cost of
                                   the row's cluster -- the rows of the result table (refine.py:426-427)
                                   in one block, written when the batch is done: what a pipeline sends

@@ -345,6 +345,23 @@ static void eval_constraints(const ctx_t* c, const double* v, double* cv, double
  * ring and disc are not "continuous" (fitfunc.py:195-204): their r2 is NaN within one pixel of
  * the centre (r2_*_safe, fitfunc.py:20-26,43-49,67-73,91-98): nansum skips those pixels for the
  * ring; the disc has the value 1 there (its function only overwrites where r2 > disc_size^2). */
+/* inv_series_<N> (fitfunc.py:148-154): g = e[0] / y(r2) with y = np.polyval([1, e[1], ..., e[N]], r2)
+ * = r2^N + e[1] r2^(N-1) + ... + e[N], evaluated in polyval's (Horner's) order; nx = N + 1 profile
+ * parameters 'signal_mult', 'param_a', ... (fitfunc.py:334-343).  "continuous": the plain r2.  The
+ * reference has no derivative of it (SLSQP differentiates the objective numerically); these are
+ * the analytic ones: dg/dr2 = -e[0] y'/y^2, dg/de[0] = 1/y, dg/de[k] = -e[0] r2^(N-k)/y^2. */
+#define INV_NX 7
+static void profile_inv(int nx, double r2, const double* e, double* g, double* dg_dr2, double* dg_de) {
+  double y = 1., dy = 0.;
+  for (int t = 1; t < nx; ++t) { dy = dy * r2 + y; y = y * r2 + e[t]; }
+  const double inv = 1. / y, c = -e[0] * (inv * inv);
+  *g = e[0] / y;
+  *dg_dr2 = c * dy;
+  dg_de[0] = inv;
+  double pw = 1.;
+  for (int t = nx - 1; t >= 1; --t) { dg_de[t] = c * pw; pw *= r2; }
+}
+
 static void profile(int fit, int nd, double r2, double e, double* g, double* dg_dr2, double* dg_de) {
   if (fit == CTR_FIT_RING) {
     const double r = sqrt(r2), num = r - 1. + e;
@@ -459,12 +476,16 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
               dr2[nd + a] = d * d * (-2. / (sz * sz * sz));
             }
           }
-          double gv, dg, dge;
+          double gv, dg, dge, dgx[INV_NX];
           const int fit = c->p->fit_function;
+          const int nx = np - (2 + nd + L->nsz);   /* profile parameters behind the sizes */
           /* r2_*_safe (fitfunc.py:20-26,...): within one pixel of the centre the profiles that are
            * not continuous have no value; nansum skips the pixel (it still counts in P) */
           const double extra = np > 2 + nd + L->nsz ? prm[np - 1] : 0.;
-          if (fit != CTR_FIT_GAUSS && qraw < 1.) {
+          if (fit == CTR_FIT_INV_SERIES) {
+            profile_inv(nx, r2, prm + 2 + nd + L->nsz, &gv, &dg, dgx);
+            dge = 0.;
+          } else if (fit != CTR_FIT_GAUSS && qraw < 1.) {
             /* (disc_func starts from ones and only overwrites where r2 > disc_size^2, false for a
              *  NaN: the disc has the value 1 there, fitfunc.py:122-131; disc_size <= 0: gauss(NaN)) */
             if (fit == CTR_FIT_DISC && extra > 0.) gv = 1.;
@@ -482,10 +503,12 @@ static void eval_cluster(const ctx_t* c, const double* v, double* S_out, double*
           }
           if (g) {
             /* d res / d signal, positions, sizes (fitfunc.py:475-478, sign of the residual) */
-            double d[1 + 6 + 1];
+            double d[CTR_MAX_PARAMS];
             d[0] = -gv;
             for (int t = 0; t < nd + L->nsz; ++t) d[1 + t] = -sig * dg * dr2[t];
-            if (np > 2 + nd + L->nsz) d[1 + nd + L->nsz] = -sig * dge;   /* fitfunc.py:480-481 */
+            if (fit == CTR_FIT_INV_SERIES)
+              for (int t = 0; t < nx; ++t) d[1 + nd + L->nsz + t] = -sig * dgx[t];
+            else if (np > 2 + nd + L->nsz) d[1 + nd + L->nsz] = -sig * dge;   /* fitfunc.py:480-481 */
             for (int k = 1; k < np; ++k) {
               int b = L->var_of[k];
               if (b < 0) continue;
@@ -1366,7 +1389,7 @@ static void frame_max(const ctr_batch* b, int nd, double* fmax) {
 
 int ctro_refine_batch(const ctr_problem* p, const ctr_batch* b, int n_threads) {
   double* fmax = malloc(sizeof(double) * (size_t)(b->n_frames > 0 ? b->n_frames : 1));
-  if (p->ndim < 2 || p->ndim > 3 || p->max_iter < 1 || p->fit_function < CTR_FIT_GAUSS || p->fit_function > CTR_FIT_DISC) { free(fmax); return CTR_ERR_INVALID; }
+  if (p->ndim < 2 || p->ndim > 3 || p->max_iter < 1 || p->fit_function < CTR_FIT_GAUSS || p->fit_function > CTR_FIT_INV_SERIES || p->n_params > CTR_MAX_PARAMS) { free(fmax); return CTR_ERR_INVALID; }
   frame_max(b, p->ndim, fmax);
   if (n_threads < 1) n_threads = 1;
 #pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads)

@@ -105,8 +105,11 @@ def is_solver_specific(name):
     # big_cluster_close_pairs: one cluster of 80 features with start positions 0.4-0.7 px apart (the
     # large-cluster path; the reference's DEFAULT run fails on it at its 100 iterations, its converged
     # run ends at cost 0.015501, the engine at 0.015488: compared by cost)
+    # inv3_2d_a_sizevar: inv_series_3 with free anisotropic sizes; the reference's SLSQP, on its
+    # numerical gradient, gives up on 13 of the 19 features ("Inequality constraints incompatible");
+    # the clusters it fits agree to 1.4e-7 px
     return name.startswith('hard_cons_') or name.startswith('tetramer2d_') or \
-        name in ('ring_2d_a_thickness', 'big_cluster_close_pairs')
+        name in ('ring_2d_a_thickness', 'big_cluster_close_pairs', 'inv3_2d_a_sizevar')
 
 
 # (fixture, cluster id): the reference fits it and the engine's minimiser returns NaN.  EMPTY since
@@ -174,7 +177,9 @@ def check_solver_specific(name, res, A, B, pos_columns):
 # centre drops out of the sum): in ring_2d_noisy one fitted centre sits 1.00005 px from a pixel,
 # the objective jumps by 1 % across that line and either minimiser stops against it on its side
 # (3e-5 px apart, costs equal to 1e-6 relative).  (position px, cost, other columns rtol)
-LOOSE = {'ring_2d_noisy': (1e-4, 1e-7, 1e-3)}
+# inv2_2d_free_params: free profile parameters next to the signal (nearly degenerate directions:
+# the reference, on a numerical gradient, stops 6e-4 away in signal at costs equal to 7e-14)
+LOOSE = {'ring_2d_noisy': (1e-4, 1e-7, 1e-3), 'inv2_2d_free_params': (1e-6, 1e-9, 1e-4)}
 
 
 def oracle_runner(n_threads=1):

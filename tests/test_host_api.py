@@ -81,9 +81,21 @@ def test_validate_problem_without_device():
         assert lib.ctr_validate_problem(ctypes.byref(p), msg, 256) == _abi.OK
         p = _abi.make_problem(2, True, [3, 1, 1, 1, 0, 0], (6, 6), fit_function=fit, noise_size=(1, 1))
         assert lib.ctr_validate_problem(ctypes.byref(p), msg, 256) == _abi.ERR_UNSUPPORTED
+    # inv_series_<N>: N + 1 columns behind the sizes, as many as CTR_MAX_PARAMS leaves room for
     p = _abi.make_problem(2, True, [3, 1, 1, 1, 0], (6, 6))
-    p.fit_function = _abi.FIT_INV_SERIES
+    p.fit_function = _abi.FIT_INV_SERIES    # ... at least 'signal_mult'
+    assert lib.ctr_validate_problem(ctypes.byref(p), msg, 256) == _abi.ERR_INVALID
+    p = _abi.make_problem(2, True, [3, 1, 1, 1, 0] + [0] * 7, (6, 6), fit_function='inv_series_6')
+    assert p.n_params == 12 == _abi.MAX_PARAMS and lib.ctr_validate_problem(ctypes.byref(p), msg, 256) == _abi.OK
+    p = _abi.make_problem(3, False, [3, 1, 1, 1, 1, 0, 0, 0, 0, 3, 1, 0], (4, 6, 6), fit_function='inv_series_3')
+    assert lib.ctr_validate_problem(ctypes.byref(p), msg, 256) == _abi.OK
+    assert lib.ctr_cluster_n_vars(ctypes.byref(p), 3) == 2 + 3 * 5
+    with pytest.raises(NotImplementedError):
+        _abi.make_problem(3, False, [0] * 13, (4, 6, 6), fit_function='inv_series_4')
+    p.n_params = 13
     assert lib.ctr_validate_problem(ctypes.byref(p), msg, 256) == _abi.ERR_UNSUPPORTED
+    p.fit_function = 4
+    assert lib.ctr_validate_problem(ctypes.byref(p), msg, 256) == _abi.ERR_INVALID
     p = _abi.make_problem(2, True, [3, 1, 1, 1, 0], (6, 6), max_iter=0)
     assert lib.ctr_validate_problem(ctypes.byref(p), msg, 256) == _abi.ERR_INVALID
     p = _abi.make_problem(2, True, [1, 1, 1, 1, 0], (6, 6))
@@ -124,10 +136,13 @@ def test_default_modes_and_layout():
     assert ff.modes == [3, 1, 1, 1, 0, 0, 3] and ff.default['thickness'] == 0.5 and not ff.continuous
     ff = cta.FitFunctions('disc', 3, True)
     assert ff.params[-1] == 'disc_size' and ff.modes[-1] == 0 and ff.default['disc_size'] == 0.5
-    with pytest.raises(NotImplementedError):
-        cta.FitFunctions('inv_series_3', 2, True)
-    with pytest.raises(ValueError):
-        cta.FitFunctions('lorentz', 2, True)
+    # fitfunc.py:334-343: generated names, all 1 by default, "continuous"
+    ff = cta.FitFunctions('inv_series_3', 2, True, dict(param_b='var'))
+    assert ff.params[-4:] == ['signal_mult', 'param_a', 'param_b', 'param_c'] and ff.continuous
+    assert ff.modes == [3, 1, 1, 1, 0, 0, 0, 1, 0] and ff.default['param_c'] == 1.
+    for bad in ('lorentz', 'inv_series', 'inv_series_x', 'gauss_2'):
+        with pytest.raises(ValueError):
+            cta.FitFunctions(bad, 2, True)
     with pytest.warns(UserWarning):
         ff = cta.FitFunctions('gauss', 2, True, dict(background='var'))
     assert ff.modes[0] == 3
@@ -136,8 +151,7 @@ def test_default_modes_and_layout():
 def test_unsupported_is_loud(oracle):
     im, truth, f0 = small_problem()
     run = _cases.oracle_runner()
-    for kw in (dict(param_mode=dict(signal='global')), dict(fit_function='inv_series_2'),
-               dict(fit_function=dict(params=[], func=None))):
+    for kw in (dict(param_mode=dict(signal='global')), dict(fit_function=dict(params=[], func=None))):
         with pytest.raises(NotImplementedError):
             _cases.refine_leastsq(f0.copy(), im, 13, _run_batch=run, **kw)
     # compute_error goes with every param_mode (second derivatives in all variables)
