@@ -63,7 +63,7 @@ constexpr int LARGE_AGG_STRIDE = 512;   // >= (4 * 7) (4 * 7 + 1) / 2 = 406 pack
 
 struct LargeWs {
   long long nvp, nvp_i;   // variables / features rounded up to a multiple of 8
-  long long o_vec, o_cur, o_mco, o_fpar, o_pre, o_uq, o_tile, o_off, o_offc, o_int, o_sync, o_pre2, o_agg, o_pix, cap, total;
+  long long o_vec, o_cur, o_mco, o_fpar, o_pre, o_uq, o_tile, o_off, o_offc, o_int, o_sync, o_pre2, o_agg, o_pix, o_pixv, cap, total;
 };
 
 // n features, npf per-feature and ns shared variables
@@ -90,11 +90,13 @@ __host__ __device__ inline LargeWs large_ws(int n, int npf, int ns, long long ca
   W.o_pre2 = o; o += (nn / 2 + 1) * LARGE_AGG_STRIDE;
   W.o_agg = o;  o += (3 * W.nvp_i + 4 * (nn / 2 + 1) + 8 + 1) / 2 + 8;
   // the mask pixels of every feature, compacted (int32: box coordinates, 10 bits per axis), rebuilt
-  // every re-window round: [n] counts, then n lists of `cap` entries
+  // every re-window round: [n] counts, then n lists of `cap` entries; their values as doubles
   W.cap = (cap + 63) & ~63LL;
-  // ... and, per feature, the pixels it shares with each neighbour j > i (a pool of `cap` entries
-  // per feature, [n][LARGE_MAXNB] offsets and counts; a pair that does not fit: count -1)
-  W.o_pix = o;  o += (W.nvp_i + 2 * nn * W.cap + 2 * nn * LARGE_MAXNB + 1) / 2 + 8;
+  W.o_pixv = o; o += nn * W.cap;
+  // ... and, per feature, the pixels it shares with each neighbour (a pool of 2 `cap` entries of
+  // two int32 -- position in the feature's list, packed coordinates -- per feature,
+  // [n][LARGE_MAXNB] offsets and counts; a pair that does not fit: count -1)
+  W.o_pix = o;  o += (W.nvp_i + 5 * nn * W.cap + 2 * nn * LARGE_MAXNB + 1) / 2 + 8;
   o = (o + 15) & ~15LL;
   W.o_sync = o; o += 64;                         // leader / helper words (large_kernel.h: LSY_*), zero at plan creation
   W.total = (o + 31) & ~31LL;

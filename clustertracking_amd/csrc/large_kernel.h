@@ -31,7 +31,10 @@ constexpr int LT = LW * WAVE;      // threads
 constexpr int LRS = 17;            // row stride of a wave's LDS tile (odd: conflict-free ds_write_b64)
 constexpr int LRED = 12;           // values per wave in the reduction scratch
 constexpr int LQT = 9;             // second-order entries per feature (block_kernel.h: QT)
-constexpr int LNB = 17;            // doubles per neighbour in a wavefront's LDS table (odd stride)
+constexpr int LNB = 19;            // doubles per neighbour in a wavefront's LDS table: 13 derived constants, (index, reverse slot), list
+                                   // cursor, mask centre relative to the window, (offset, length) of the pair's list
+                                   // (read with one address for all lanes)
+constexpr int LREG = 1408;         // doubles of a wavefront's LDS region: that table + the neighbours' sums per pixel
 
 struct SmemL {
   static constexpr int o_rows = 0;                       // LW row tiles of 64 x LRS; the CG's vectors during a solve
@@ -40,9 +43,10 @@ struct SmemL {
   static constexpr int o_tot = o_red + LW * LRED;        // 256 sums over the features of the tiles
   static constexpr int o_sh = o_tot + 256;               // shared-variable scratch: 8 x 8 + 6 x 8
   // per wavefront: the constants of the neighbours of the feature it is working on
-  // (LARGE_MAXNB x LNB doubles: 13 derived constants, mask centre relative to the window, index)
+  // (<= LARGE_MAXNB x LNB doubles), then the neighbours' model sums of a segment of its pixels
   static constexpr int o_nb = o_sh + 64 + 48;
-  static constexpr int total = o_nb + LW * LARGE_MAXNB * 17;
+  static constexpr int total = o_nb + LW * LREG;
+  static_assert(LREG >= LARGE_MAXNB * LNB + 7 * 64 + 8, "room for one tile of pixels (model sum + 6 shared columns) behind a full table");
   static constexpr size_t bytes = (size_t)total * sizeof(double);
 };
 
@@ -119,6 +123,25 @@ __device__ __forceinline__ void acquire_agent() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- X^T X with v_mfma_f64_4x4x4_4b_f64 ------------------------------------------------------------
+// The rows of a wavefront's LDS tile (64 pixels x <= 16 columns) hold few live columns: 8 for the
+// default modes ([r, bg, signal, z, y, x, r_o, bg_o]), two 4-column groups of a pair's block.  The
+// 16 x 16 x 4 instruction spends 64 cycles per 4 pixels on 256 outputs whatever the columns hold
+// (1024 cycles per tile); the 4 x 4 x 4 form (4 blocks of 4 x 4 x 4, 16 cycles) multiplies one
+// 4-column group by another for 16 pixels: its blocks serve as four more steps of the sum, added
+// up once per feature.  Operand layout (probed on gfx950, tools/mfma_probe.hip):
+// A[blk][i][k] in lane 16 k + 4 blk + i, B[blk][k][j] in lane 16 k + 4 blk + j, D[blk][i][j] in lane
+// 16 i + 4 blk + j: lane l feeds column (l & 3) of its group for pixel l >> 2 of the 16.
+__device__ __forceinline__ double mfma4_group(const double* rows, int step, int group, int lane) {
+  return rows[(16 * step + (lane >> 2)) * LRS + 4 * group + (lane & 3)];
+}
+// sum of the four blocks: afterwards lane 16 i + j (and its three copies) holds entry (i, j)
+__device__ __forceinline__ double mfma4_total(double v) {
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+
 // LP: with the lowpass of the window (ctr_problem.noise_size; device_common.h:lowpass_pixel)
 template <int ND, bool ISO, bool LP = false>
 __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double* __restrict__ ws_base,
@@ -164,8 +187,11 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
   unsigned long long* sy = (unsigned long long*)(ws + W.o_sync);   // leader / helper words (LSY_*)
   int* pix_cnt = (int*)(ws + W.o_pix);         // mask pixels of feature i: count, then the list
   int* pix_list = pix_cnt + W.nvp_i;
-  int* pair_pool = pix_list + (size_t)n * W.cap;   // pixels shared with the neighbours j > i
-  int* pair_off = pair_pool + (size_t)n * W.cap;
+  double* pix_val = ws + W.o_pixv;        // ... and the pixels' values (after the lowpass, if any)
+  // the pixels a feature shares with each of its neighbours: (position in its own list, packed box
+  // coordinates), a pool of 2 * cap entries per feature
+  int2* pair_pool = (int2*)(pix_list + (size_t)n * W.cap);
+  int* pair_off = (int*)(pair_pool + (size_t)n * 2 * W.cap);
   int* pair_cnt = pair_off + (size_t)n * LARGE_MAXNB;
   // aggregates of the preconditioner: strongly coupled features share one diagonal block
   double* pre2 = ws + W.o_pre2;
@@ -225,6 +251,13 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
   auto pass_features = [&](double* tile, double* off, double bgv, unsigned seq) {
     int Pown = 0, taken = 0;
     const bool bg_var = L.slot[0] >= 0;
+    // shared variables that collect the features' derivative columns (any 'cluster'-mode column
+    // besides the background)
+    int nsh2 = 0;
+#pragma unroll
+    for (int kk = 1; kk < NP; ++kk) nsh2 += (L.slot[kk] >= 0 && !L.per_feat[kk]) ? 1 : 0;
+    // 4-column groups of the own tile's live columns and of a pair's d_i / d_j
+    const int G4 = (2 + 2 * NS + NPF + 3) >> 2, GP = (NPF + 3) >> 2;
     while (true) {
       // claim the next feature of THIS pass (the counter carries the pass number: a wavefront
       // that is late for a pass that has ended can never take a feature of the next one)
@@ -257,209 +290,337 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       const int cnt = nbcnt[i];
       const int* nb = nbidx + (size_t)i * LARGE_MAXNB;
       // This feature's constants in registers; its neighbours' are read from the workspace once
-      // per feature, not once per tile and neighbour (dependent L2 round trips made a tile cost
-      // 14 us).
+      // per feature into the wavefront's LDS table (dependent L2 round trips per tile and
+      // neighbour made a tile cost 14 us): 13 derived constants, index, list cursor, mask centre.
       double fi[13];
 #pragma unroll
       for (int q2 = 0; q2 < 13; ++q2) fi[q2] = fpar[(size_t)i * FP + q2];
-      // neighbour l's mask centre stays in the registers of LANE l (the per-tile box test); its
-      // derived constants and index go to this wavefront's LDS table, read back with one address
-      // for all lanes (a broadcast) where a tile needs them.  (Round 2 kept all of it in lane
-      // registers and broadcast with v_readlane: 33 registers in a kernel that spills 500 bytes per
-      // lane, 32 lane reads per candidate.)
-      double nrel[ND];
-      double* nbl = smem + SmemL::o_nb + wave * (LARGE_MAXNB * LNB);
-#pragma unroll
-      for (int a = 0; a < ND; ++a) nrel[a] = 0.;
+      double* reg = smem + SmemL::o_nb + wave * LREG;
       if (lane < cnt) {
         const int njl = nb[lane];
 #pragma unroll
-        for (int a = 0; a < ND; ++a) { nrel[a] = mco[njl * 3 + a] - (double)origin[a]; nbl[lane * LNB + 13 + a] = nrel[a]; }
+        for (int q2 = 0; q2 < 13; ++q2) reg[lane * LNB + q2] = fpar[(size_t)njl * FP + q2];
+        *(int2*)(reg + lane * LNB + 13) = make_int2(njl, rev[(size_t)i * LARGE_MAXNB + lane]);
+        reg[lane * LNB + 14] = 0.;
 #pragma unroll
-        for (int q2 = 0; q2 < 13; ++q2) nbl[lane * LNB + q2] = fpar[(size_t)njl * FP + q2];
-        nbl[lane * LNB + 16] = (double)njl;
+        for (int a = 0; a < ND; ++a) reg[lane * LNB + 15 + a] = mco[njl * 3 + a] - (double)origin[a];
+        *(int2*)(reg + lane * LNB + 18) = make_int2(pair_off[(size_t)i * LARGE_MAXNB + lane], pair_cnt[(size_t)i * LARGE_MAXNB + lane]);
       }
+      // Behind the table, in what is left of the wavefront's region: per pixel of a SEGMENT of
+      // the feature's list the sum of the neighbours' models (and of their derivative columns of
+      // the shared variables, if there are any besides the background), and one byte "this
+      // feature is the lowest that covers the pixel".  cfg 3: 1072 pixels, ~12 neighbours: one
+      // segment.
+      double* accb = reg + cnt * LNB;
+      const int SEG = (((LREG - cnt * LNB) * 8) / (8 * (1 + nsh2) + 1)) & ~63;
+      unsigned char* ownf = (unsigned char*)(accb + SEG * (1 + nsh2));
       wsync();
       const unsigned long long tf0 = LDBG_NOW();
-      v4d acc = v4d{0., 0., 0., 0.};
+      // accumulators of the own tile: one per pair (ga <= gb) of 4-column groups
+      double accq[10];
+#pragma unroll
+      for (int t = 0; t < 10; ++t) accq[t] = 0.;
       constexpr int NUF = ND * (ND + 1) / 2;
       double uacc[NUF];
 #pragma unroll
       for (int t = 0; t < NUF; ++t) uacc[t] = 0.;
       double* row = myrows + lane * LRS;
       // the mask pixels of feature i from its list (built once per re-window round, box order):
-      // 64 of them per tile, every lane at work -- 41 % of a 9 x 17 x 17 box is mask
+      // packed box coordinates and the pixel's value; 64 of them per tile, every lane at work --
+      // 41 % of a 9 x 17 x 17 box is mask
       const int npl = pix_cnt[i];
       const int* plist = pix_list + (size_t)i * W.cap;
-      for (int base = 0; base < npl; base += WAVE) {
+      const double* pvals = pix_val + (size_t)i * W.cap;
+      const int2* pool = pair_pool + (size_t)i * (2 * W.cap);
+      constexpr int PK_NAN = 1 << 30;   // (pair entry: the pixel of the image is NaN)
+      for (int q0 = 0; q0 < npl; q0 += SEG) {
+        const int q1 = q0 + SEG < npl ? q0 + SEG : npl;
+        for (int e = lane; e < SEG * (1 + nsh2); e += WAVE) accb[e] = 0.;
+        for (int e = lane; e < SEG; e += WAVE) ownf[e] = 1;
+        wsync();
+        // ---- One visit per neighbour over the pixels it shares with feature i (the pair's list:
+        // positions in i's list, ascending, and coordinates; every lane at work): its model into
+        // the pixels' sums, and for j > i the block d_i d_j^T of the normal matrix.  The first
+        // tile of the next neighbour's list is fetched while this one is worked on (a visit is
+        // one L2 / HBM round trip otherwise: the wavefront has one companion on its SIMD).
         const unsigned long long tc_a = LDBG_CYC();
-        const int q = base + lane;
-        int idx[ND];
-        const bool in_i = q < npl;
-        size_t offp = 0;
-        int cb[ND];          // box coordinates of this lane's pixel
+        int2 en_next = make_int2(0x7fffffff, 0);
         {
-          const int pk = in_i ? plist[q] : 0;
-#pragma unroll
-          for (int a = 0; a < ND; ++a) cb[a] = (pk >> (10 * (ND - 1 - a))) & 1023;
+          const double* t0 = reg;
+          const int2 oc = cnt > 0 ? *(const int2*)(t0 + 18) : make_int2(0, 0);
+          const int e0 = (int)t0[14] + lane;
+          if (cnt > 0 && oc.y >= 0 && e0 < oc.y) en_next = pool[oc.x + e0];
         }
-        // Which neighbours can touch this tile at all?  Lane l tests the box of neighbour l
-        // (centre +- radius, a superset of its mask) against the index extent of the 64 list
-        // pixels (box order: the slowest axis runs from the first lane's to the last lane's
-        // value; an axis below one that changes spans its whole range): one ballot gives the
-        // candidates (as in block_kernel.h).
-        unsigned long long cand;
-        {
-          const int last = (base + WAVE - 1 < npl ? WAVE - 1 : npl - 1 - base);
-          int lo_i[ND], hi_i[ND];
-          bool same = true;   // all slower axes equal so far
-#pragma unroll
-          for (int a = 0; a < ND; ++a) {
-            const int c0 = __builtin_amdgcn_readfirstlane(cb[a]);
-            const int c1 = __builtin_amdgcn_readlane(cb[a], last);
-            lo_i[a] = blo[a] + (same ? c0 : 0);
-            hi_i[a] = blo[a] + (same ? c1 : bsz[a] - 1);
-            same = same && c0 == c1;
+        for (int s2 = 0; s2 < cnt; ++s2) {
+          double* tj = reg + s2 * LNB;
+          const int2 jr = *(const int2*)(tj + 13);   // the neighbour and i's place in ITS list
+          const int j = jr.x;
+          const int2 oc = *(const int2*)(tj + 18);
+          const int pc = oc.y;
+          const int2* ppl = pool + oc.x;
+          const bool pairblk = j > i;
+          int2 en_cur = en_next;
+          en_next = make_int2(0x7fffffff, 0);
+          if (s2 + 1 < cnt) {
+            const double* tn = tj + LNB;
+            const int2 ocn = *(const int2*)(tn + 18);
+            const int e0 = (int)tn[14] + lane;
+            if (ocn.y >= 0 && e0 < ocn.y) en_next = pool[ocn.x + e0];
           }
-          bool hit = lane < cnt;
+          double accp[4];   // (group of d_i, group of d_j)
 #pragma unroll
-          for (int a = 0; a < ND; ++a)
-            hit = hit && ((double)hi_i[a] >= nrel[a] - (double)radius[a]) && ((double)lo_i[a] <= nrel[a] + (double)radius[a]);
-          cand = __ballot(hit);
-        }
+          for (int t = 0; t < 4; ++t) accp[t] = 0.;
+          const unsigned long long tv0 = LDBG_CYC();
+          unsigned long long tmf = 0ull;
+          // (a pair whose list did not fit the pool: the segment of i's own list, mask test per pixel)
+          int e = pc >= 0 ? (int)tj[14] : q0;
+          const int eend = pc >= 0 ? pc : q1;
+          bool first = true;
+          while (e < eend) {
+            const int ee = e + lane;
+            int qi = 0x7fffffff, pk = 0;
+            if (pc >= 0) {
+              if (first) { qi = en_cur.x; pk = en_cur.y; }
+              else if (ee < eend) { const int2 en = ppl[ee]; qi = en.x; pk = en.y; }
+            } else if (ee < eend) {
+              qi = ee;
+              pk = plist[ee];
+              if (pvals[ee] != pvals[ee]) pk |= PK_NAN;
+            }
+            first = false;
+            bool in = qi < q1;
+            const int m = __popcll(__ballot(in));
+            int idx[ND];
 #pragma unroll
-        for (int a = 0; a < ND; ++a) idx[a] = in_i ? blo[a] + cb[a] : 0;
-        if (in_i) {
-          if (ND == 3)
-            offp = ((size_t)(idx[0] + origin[0]) * fshape[1] + (idx[1] + origin[1])) * fshape[ND - 1] + (idx[ND - 1] + origin[ND - 1]);
-          else
-            offp = (size_t)(idx[0] + origin[0]) * fshape[ND - 1] + (idx[ND - 1] + origin[ND - 1]);
-        }
-#pragma unroll
-        for (int c2 = 0; c2 < 16; ++c2) row[c2] = 0.;
-        {
-          // (all lanes run the neighbour loop -- v_readlane must not sit in divergent control
-          //  flow: a spilled source register is reloaded for the active lanes only)
-          double pix = 0.;
-          if (in_i) {
-            if constexpr (LP) pix = lowpass_pixel<ND>(frame, k.frame_dtype, fshape, origin, wshape, idx, k.lp_w, k.lp_half, k.prob.threshold);
-            else pix = load_pixel(frame, k.frame_dtype, offp);
-          }
-          double res = pix - bgv;
-          const unsigned long long tc_b = LDBG_CYC();
-          bool owner = true;
-          double shared[CTR_MAX_PARAMS], down[1 + ND + NSZ];
-#pragma unroll
-          for (int kk = 0; kk < CTR_MAX_PARAMS; ++kk) shared[kk] = 0.;
-#pragma unroll
-          for (int t = 0; t < 1 + ND + NSZ; ++t) down[t] = 0.;
-          double Eown[ND];
-#pragma unroll
-          for (int a = 0; a < ND; ++a) Eown[a] = 0.;
-          // the features that cover this pixel: i itself and the tile's candidate neighbours
-          // (ascending order)
-          unsigned long long todo = cand;
-          for (int s2 = -1;;) {
-            double f[13];
-            bool covered = in_i;
-            if (s2 < 0) {
-#pragma unroll
-              for (int q2 = 0; q2 < 13; ++q2) f[q2] = fi[q2];
-            } else {
+            for (int a = 0; a < ND; ++a) idx[a] = blo[a] + ((pk >> (10 * (ND - 1 - a))) & 1023);
+            if (pc < 0 && in) {
               double rel[ND];
 #pragma unroll
-              for (int a = 0; a < ND; ++a) rel[a] = nbl[s2 * LNB + 13 + a];
-              covered = in_i && in_mask<ND>(idx, rel, inv_r2, radius);
-              const int j = (int)nbl[s2 * LNB + 16];
-              if (covered && j < i) owner = false;
-              // (a candidate by its box that covers none of the 64 pixels: nothing to load)
-              if (__ballot(covered) != 0ull) {
-#pragma unroll
-                for (int q2 = 0; q2 < 13; ++q2) f[q2] = nbl[s2 * LNB + q2];
-              } else {
-#pragma unroll
-                for (int q2 = 0; q2 < 13; ++q2) f[q2] = 0.;
-              }
+              for (int a = 0; a < ND; ++a) rel[a] = tj[15 + a];
+              in = in_mask<ND>(idx, rel, inv_r2, radius);
             }
-            if (covered) {
-            double r2 = 0., dd[ND], d[1 + ND + NSZ];
+            if (pairblk) {
 #pragma unroll
-            for (int a = 0; a < ND; ++a) {
-              dd[a] = (double)(idx[a] + origin[a]) - f[1 + a];
-              r2 += dd[a] * dd[a] * f[4 + a];
+              for (int c2 = 0; c2 < 16; ++c2) row[c2] = 0.;
             }
-            const double gv = exp(-0.5 * ND * r2);  // fitfunc.py:112-118
-            const double sig = f[0];
-            const double sdg = sig * (0.5 * ND) * gv;
-            res -= sig * gv;
-            d[0] = -gv;
-            double q2 = 0.;
-#pragma unroll
-            for (int a = 0; a < ND; ++a) {
-              d[1 + a] = sdg * (-dd[a] * f[7 + a]);
-              if (ISO) q2 += dd[a] * dd[a];
-              else d[1 + ND + a] = sdg * (dd[a] * dd[a] * f[10 + a]);
-            }
-            if (ISO) d[1 + ND] = sdg * (q2 * f[10]);
-#pragma unroll
-            for (int kk = 1; kk < NP; ++kk) shared[kk] += d[kk - 1];
-            if (s2 < 0) {
-#pragma unroll
-              for (int t = 0; t < 1 + ND + NSZ; ++t) down[t] = d[t];
-#pragma unroll
-              for (int a = 0; a < ND; ++a) Eown[a] = (double)ND * (dd[a] * f[4 + a]);
-            }
-            }
-            // next candidate
-            if (todo == 0ull) break;
-            s2 = __builtin_ctzll(todo);
-            todo &= todo - 1ull;
-          }
-          const unsigned long long tc_c = LDBG_CYC();
-          if (tid == 0 && !helper) { LDBG_ADD(24, tc_b - tc_a); LDBG_ADD(25, tc_c - tc_b); }
-          (void)tc_a; (void)tc_b; (void)tc_c;
-          Pown += (in_i && owner) ? 1 : 0;
-          if (in_i && res == res) {   // nansum (fitfunc.py:449,483): a NaN pixel counts in P only
-            const double ow = owner ? 1. : 0.;
-            row[0] = res;
-            row[c_reso] = ow * res;
-            if (bg_var) { row[1 + L.slot[0]] = -1.; row[c_sho + L.slot[0]] = -ow; }
-#pragma unroll
-            for (int kk = 1; kk < NP; ++kk) {
-              if (L.slot[kk] < 0) continue;
-              if (L.per_feat[kk]) row[c_own + L.slot[kk]] = down[kk - 1];
-              else { row[1 + L.slot[kk]] = shared[kk]; row[c_sho + L.slot[kk]] = ow * shared[kk]; }
-            }
-            if (newton_on) {
-              int e = 0;
+            if (in) {
+              double r2 = 0., dd[ND], d[1 + ND + NSZ];
 #pragma unroll
               for (int a = 0; a < ND; ++a) {
-                const double rj = res * down[1 + a];
+                dd[a] = (double)(idx[a] + origin[a]) - tj[1 + a];
+                r2 += dd[a] * dd[a] * tj[4 + a];
+              }
+              const double gv = exp(-0.5 * ND * r2);  // fitfunc.py:112-118
+              const double sig = tj[0];
+              accb[qi - q0] += sig * gv;
+              if (j < i) ownf[qi - q0] = 0;
+              if (nsh2 > 0 || pairblk) {
+                const double sdg = sig * (0.5 * ND) * gv;
+                d[0] = -gv;
+                double qq = 0.;
 #pragma unroll
-                for (int b2 = a; b2 < ND; ++b2) { uacc[e] += rj * Eown[b2]; ++e; }
+                for (int a = 0; a < ND; ++a) {
+                  d[1 + a] = sdg * (-dd[a] * tj[7 + a]);
+                  if (ISO) qq += dd[a] * dd[a];
+                  else d[1 + ND + a] = sdg * (dd[a] * dd[a] * tj[10 + a]);
+                }
+                if (ISO) d[1 + ND] = sdg * (qq * tj[10]);
+                if (nsh2 > 0) {
+                  int t = 1;
+#pragma unroll
+                  for (int kk = 1; kk < NP; ++kk)
+                    if (L.slot[kk] >= 0 && !L.per_feat[kk]) { accb[t * SEG + qi - q0] += d[kk - 1]; ++t; }
+                }
+                if (pairblk && (pk & PK_NAN) == 0) {   // (a NaN pixel of the image contributes nothing)
+#pragma unroll
+                  for (int kk = 1; kk < NP; ++kk)
+                    if (L.slot[kk] >= 0 && L.per_feat[kk]) row[8 + L.slot[kk]] = d[kk - 1];
+                  // ... and feature i's own derivatives at the pixel
+                  double r2i = 0.;
+#pragma unroll
+                  for (int a = 0; a < ND; ++a) {
+                    dd[a] = (double)(idx[a] + origin[a]) - fi[1 + a];
+                    r2i += dd[a] * dd[a] * fi[4 + a];
+                  }
+                  const double gvi = exp(-0.5 * ND * r2i);
+                  const double sdgi = fi[0] * (0.5 * ND) * gvi;
+                  d[0] = -gvi;
+                  qq = 0.;
+#pragma unroll
+                  for (int a = 0; a < ND; ++a) {
+                    d[1 + a] = sdgi * (-dd[a] * fi[7 + a]);
+                    if (ISO) qq += dd[a] * dd[a];
+                    else d[1 + ND + a] = sdgi * (dd[a] * dd[a] * fi[10 + a]);
+                  }
+                  if (ISO) d[1 + ND] = sdgi * (qq * fi[10]);
+#pragma unroll
+                  for (int kk = 1; kk < NP; ++kk)
+                    if (L.slot[kk] >= 0 && L.per_feat[kk]) row[L.slot[kk]] = d[kk - 1];
+                }
+              }
+            }
+            if (pairblk) {
+              wsync();
+              const unsigned long long tm0 = LDBG_CYC();
+#pragma unroll
+              for (int st = 0; st < 4; ++st) {
+                double xi[2], xj[2];
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                  xi[g2] = g2 < GP ? mfma4_group(myrows, st, g2, lane) : 0.;
+                  xj[g2] = g2 < GP ? mfma4_group(myrows, st, 2 + g2, lane) : 0.;
+                }
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                  for (int gj = 0; gj < 2; ++gj)
+                    if (gi < GP && gj < GP) accp[2 * gi + gj] = __builtin_amdgcn_mfma_f64_4x4x4f64(xi[gi], xj[gj], accp[2 * gi + gj], 0, 0, 0);
+              }
+              wsync();
+              tmf += LDBG_CYC() - tm0;
+            }
+            e += m;
+            if (m < WAVE) break;
+          }
+          if (pc >= 0 && lane == 0) tj[14] = (double)e;
+          const unsigned long long tv1 = LDBG_CYC();
+          if (pairblk) {
+            // columns 0..7 of the rows = d_i, 8..15 = d_j: lane = entry (a, b) of the 8 x 8 block, its
+            // value in lane 16 (a & 3) + (b & 3) of the accumulator of groups (a >> 2, b >> 2); both
+            // directions; a later segment of i's list adds to the first one's sums
+            const int a8 = lane >> 3, b8 = lane & 7;
+            double x = 0.;
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+              for (int gj = 0; gj < 2; ++gj) {
+                const double v = __shfl(mfma4_total(accp[2 * gi + gj]), 16 * (a8 & 3) + (b8 & 3));
+                if ((a8 >> 2) == gi && (b8 >> 2) == gj && gi < GP && gj < GP) x = v;
+              }
+            double* oij = off + ((size_t)i * LARGE_MAXNB + s2) * 64;
+            double* oji = off + ((size_t)j * LARGE_MAXNB + jr.y) * 64;
+            if (q0 != 0) x += oij[a8 * 8 + b8];
+            oij[a8 * 8 + b8] = x;
+            oji[b8 * 8 + a8] = x;
+          }
+          wsync();   // (the next neighbour may cover the same pixels)
+          if (tid == 0 && !helper) {
+            if (pairblk) { LDBG_ADD(28, tv1 - tv0); LDBG_ADD(29, 1); LDBG_ADD(15, tmf); LDBG_ADD(11, LDBG_CYC() - tv1); }
+            else { LDBG_ADD(30, tv1 - tv0); LDBG_ADD(31, 1); }
+          }
+          (void)tv0; (void)tv1; (void)tmf;
+        }
+        const unsigned long long tc_b = LDBG_CYC();
+        if (tid == 0 && !helper) LDBG_ADD(24, tc_b - tc_a);
+        (void)tc_a; (void)tc_b;
+        // ---- the feature's own tiles of this segment (the next tile's list entries are fetched
+        // while this one is worked on)
+        int pk_n = 0;
+        double px_n = 0.;
+        if (q0 + lane < q1) { pk_n = plist[q0 + lane]; px_n = pvals[q0 + lane]; }
+        for (int base = q0; base < q1; base += WAVE) {
+          const unsigned long long tc_c = LDBG_CYC();
+          const int q = base + lane;
+          const bool in_i = q < q1;
+          const int pk = pk_n;
+          const double pix = px_n;
+          if (q + WAVE < q1) { pk_n = plist[q + WAVE]; px_n = pvals[q + WAVE]; }
+          int idx[ND];
+#pragma unroll
+          for (int a = 0; a < ND; ++a) idx[a] = in_i ? blo[a] + ((pk >> (10 * (ND - 1 - a))) & 1023) : 0;
+#pragma unroll
+          for (int c2 = 0; c2 < 16; ++c2) row[c2] = 0.;
+          if (in_i) {
+            double r2 = 0., dd[ND], d[1 + ND + NSZ], Eown[ND];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              dd[a] = (double)(idx[a] + origin[a]) - fi[1 + a];
+              r2 += dd[a] * dd[a] * fi[4 + a];
+            }
+            const double gv = exp(-0.5 * ND * r2);  // fitfunc.py:112-118
+            const double sig = fi[0];
+            const double sdg = sig * (0.5 * ND) * gv;
+            // the features that cover this pixel: i itself, then its neighbours in list order
+            const double res = ((pix - bgv) - sig * gv) - accb[q - q0];
+            d[0] = -gv;
+            double qq = 0.;
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              d[1 + a] = sdg * (-dd[a] * fi[7 + a]);
+              if (ISO) qq += dd[a] * dd[a];
+              else d[1 + ND + a] = sdg * (dd[a] * dd[a] * fi[10 + a]);
+              Eown[a] = (double)ND * (dd[a] * fi[4 + a]);
+            }
+            if (ISO) d[1 + ND] = sdg * (qq * fi[10]);
+            const bool owner = ownf[q - q0] != 0;
+            Pown += owner ? 1 : 0;
+            if (res == res) {   // nansum (fitfunc.py:449,483): a NaN pixel counts in P only
+              const double ow = owner ? 1. : 0.;
+              row[0] = res;
+              row[c_reso] = ow * res;
+              if (bg_var) { row[1 + L.slot[0]] = -1.; row[c_sho + L.slot[0]] = -ow; }
+              int t = 1;
+#pragma unroll
+              for (int kk = 1; kk < NP; ++kk) {
+                if (L.slot[kk] < 0) continue;
+                if (L.per_feat[kk]) row[c_own + L.slot[kk]] = d[kk - 1];
+                else {
+                  const double sh = d[kk - 1] + accb[t * SEG + q - q0];
+                  ++t;
+                  row[1 + L.slot[kk]] = sh;
+                  row[c_sho + L.slot[kk]] = ow * sh;
+                }
+              }
+              if (newton_on) {
+                int e = 0;
+#pragma unroll
+                for (int a = 0; a < ND; ++a) {
+                  const double rj = res * d[1 + a];
+#pragma unroll
+                  for (int b2 = a; b2 < ND; ++b2) { uacc[e] += rj * Eown[b2]; ++e; }
+                }
               }
             }
           }
-        }
-        const unsigned long long tc_d = LDBG_CYC();
-        wsync();
-        {
-          const double* rbase = myrows + (lane >> 4) * LRS + (lane & 15);
-#pragma unroll 4
-          for (int s2 = 0; s2 < 16; ++s2) {
-            const double x = rbase[4 * s2 * LRS];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+          const unsigned long long tc_d = LDBG_CYC();
+          wsync();
+#pragma unroll
+          for (int st = 0; st < 4; ++st) {
+            double xg[4];
+#pragma unroll
+            for (int g2 = 0; g2 < 4; ++g2) xg[g2] = g2 < G4 ? mfma4_group(myrows, st, g2, lane) : 0.;
+#pragma unroll
+            for (int gb = 0; gb < 4; ++gb)
+#pragma unroll
+              for (int ga = 0; ga <= gb; ++ga)
+                if (gb < G4) accq[gb * (gb + 1) / 2 + ga] = __builtin_amdgcn_mfma_f64_4x4x4f64(xg[ga], xg[gb], accq[gb * (gb + 1) / 2 + ga], 0, 0, 0);
           }
+          wsync();
+          if (tid == 0 && !helper) { LDBG_ADD(25, tc_d - tc_c); LDBG_ADD(26, LDBG_CYC() - tc_d); LDBG_ADD(27, 1); }
+          (void)tc_c; (void)tc_d;
         }
-        wsync();
-        if (tid == 0 && !helper) { LDBG_ADD(26, LDBG_CYC() - tc_d); LDBG_ADD(27, 1); }
-        (void)tc_d;
       }
-      // D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+      // entry (4 ga + i, 4 gb + j) from lane 16 i + j of the pair's accumulator, both triangles;
+      // zeros beyond the live groups
       {
         double* t = tile + (size_t)i * 256;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) t[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
+        for (int r = 0; r < 4; ++r) {
+          const int e = lane + 64 * r;
+          if ((e >> 4) >= 4 * G4 || (e & 15) >= 4 * G4) t[e] = 0.;
+        }
+        const int ii = lane >> 4, jj = lane & 3;
+#pragma unroll
+        for (int gb = 0; gb < 4; ++gb)
+#pragma unroll
+          for (int ga = 0; ga <= gb; ++ga)
+            if (gb < G4) {
+              const double v = mfma4_total(accq[gb * (gb + 1) / 2 + ga]);
+              if ((lane & 12) == 0) {
+                t[(4 * ga + ii) * 16 + 4 * gb + jj] = v;
+                if (ga != gb) t[(4 * gb + jj) * 16 + 4 * ga + ii] = v;
+              }
+            }
       }
       if (newton_on) {
 #pragma unroll
@@ -469,123 +630,6 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         }
       }
       const unsigned long long tf1 = LDBG_NOW();
-      // ---- neighbour blocks: d_i d_j^T over mask i & mask j, for the neighbours j > i -------
-      for (int s2 = 0; s2 < cnt; ++s2) {
-        const int j = (int)nbl[s2 * LNB + 16];
-        if (j < i) continue;
-        double fj[13];
-#pragma unroll
-        for (int q2 = 0; q2 < 13; ++q2) fj[q2] = nbl[s2 * LNB + q2];
-        double rel_j[ND];
-        int plo[ND], psz[ND], np2 = 1;
-#pragma unroll
-        for (int a = 0; a < ND; ++a) {
-          rel_j[a] = nbl[s2 * LNB + 13 + a];
-          int l = (int)ceil(rel_j[a] - (double)radius[a]), u = (int)floor(rel_j[a] + (double)radius[a]);
-          l = l < blo[a] ? blo[a] : l;
-          u = u > blo[a] + bsz[a] - 1 ? blo[a] + bsz[a] - 1 : u;
-          plo[a] = l;
-          psz[a] = u >= l ? u - l + 1 : 0;
-          np2 *= psz[a];
-        }
-        acc = v4d{0., 0., 0., 0.};
-        // the pixels in both masks: from the pair's list of this round (every lane at work), or,
-        // where that did not fit its pool, by walking the intersection of the two boxes
-        const int pc = pair_cnt[(size_t)i * LARGE_MAXNB + s2];
-        const int* ppl = pair_pool + (size_t)i * W.cap + pair_off[(size_t)i * LARGE_MAXNB + s2];
-        if (pc >= 0) np2 = pc;
-        for (int base = 0; base < np2; base += WAVE) {
-          const int q = base + lane;
-          bool both = false;
-          int idx[ND];
-          size_t offp = 0;
-          if (q < np2) {
-            if (pc >= 0) {
-              const int pk = ppl[q];
-#pragma unroll
-              for (int a = 0; a < ND; ++a) idx[a] = blo[a] + ((pk >> (10 * (ND - 1 - a))) & 1023);
-              both = true;
-            } else {
-              int t = q;
-#pragma unroll
-              for (int a = ND - 1; a >= 0; --a) {
-                const int w = psz[a];
-                const int c2 = t % w;
-                t /= w;
-                idx[a] = plo[a] + c2;
-              }
-              both = in_mask<ND>(idx, rel_i, inv_r2, radius) && in_mask<ND>(idx, rel_j, inv_r2, radius);
-            }
-            if (ND == 3)
-              offp = ((size_t)(idx[0] + origin[0]) * fshape[1] + (idx[1] + origin[1])) * fshape[ND - 1] + (idx[ND - 1] + origin[ND - 1]);
-            else
-              offp = (size_t)(idx[0] + origin[0]) * fshape[ND - 1] + (idx[ND - 1] + origin[ND - 1]);
-          } else {
-#pragma unroll
-            for (int a = 0; a < ND; ++a) idx[a] = 0;
-          }
-          if (__ballot(both) == 0ull) continue;
-#pragma unroll
-          for (int c2 = 0; c2 < 16; ++c2) row[c2] = 0.;
-          if (both) {
-            double pix;
-            if constexpr (LP) pix = lowpass_pixel<ND>(frame, k.frame_dtype, fshape, origin, wshape, idx, k.lp_w, k.lp_half, k.prob.threshold);
-            else pix = load_pixel(frame, k.frame_dtype, offp);
-            if (pix == pix) {   // (a NaN pixel of the image contributes nothing)
-#pragma unroll
-              for (int side = 0; side < 2; ++side) {
-                double f[13];
-#pragma unroll
-                for (int q2 = 0; q2 < 13; ++q2) f[q2] = side == 0 ? fi[q2] : fj[q2];
-                double r2 = 0., dd[ND], d[1 + ND + NSZ];
-#pragma unroll
-                for (int a = 0; a < ND; ++a) {
-                  dd[a] = (double)(idx[a] + origin[a]) - f[1 + a];
-                  r2 += dd[a] * dd[a] * f[4 + a];
-                }
-                const double gv = exp(-0.5 * ND * r2);
-                const double sdg = f[0] * (0.5 * ND) * gv;
-                d[0] = -gv;
-                double q2 = 0.;
-#pragma unroll
-                for (int a = 0; a < ND; ++a) {
-                  d[1 + a] = sdg * (-dd[a] * f[7 + a]);
-                  if (ISO) q2 += dd[a] * dd[a];
-                  else d[1 + ND + a] = sdg * (dd[a] * dd[a] * f[10 + a]);
-                }
-                if (ISO) d[1 + ND] = sdg * (q2 * f[10]);
-#pragma unroll
-                for (int kk = 1; kk < NP; ++kk)
-                  if (L.slot[kk] >= 0 && L.per_feat[kk]) row[8 * side + L.slot[kk]] = d[kk - 1];
-              }
-            }
-          }
-          wsync();
-          {
-            const double* rbase = myrows + (lane >> 4) * LRS + (lane & 15);
-#pragma unroll 4
-            for (int s3 = 0; s3 < 16; ++s3) {
-              const double x = rbase[4 * s3 * LRS];
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
-            }
-          }
-          wsync();
-        }
-        // rows 0..7 = d_i, columns 8..15 = d_j: block (a, b) at acc[row a][col 8 + b]; both directions
-        {
-          const int col = lane & 15;
-          double* oij = off + ((size_t)i * LARGE_MAXNB + s2) * 64;
-          double* oji = off + ((size_t)j * LARGE_MAXNB + rev[(size_t)i * LARGE_MAXNB + s2]) * 64;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int rw = (lane >> 4) + 4 * r;
-            if (rw < 8 && col >= 8) {
-              oij[rw * 8 + (col - 8)] = acc[r];
-              oji[(col - 8) * 8 + rw] = acc[r];
-            }
-          }
-        }
-      }
       if (tid == 0 && !helper) { LDBG_ADD(6, tf1 - tf0); LDBG_ADD(7, LDBG_NOW() - tf1); }
       (void)tf0; (void)tf1;
     }
@@ -953,13 +997,17 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         npx *= bsz[a];
       }
       int* plist = pix_list + (size_t)i * W.cap;
+      double* pvals = pix_val + (size_t)i * W.cap;
       int filled = 0;
       for (int base = 0; base < npx; base += WAVE) {
         const int q = base + lane;
         bool in_i = false;
         int pk = 0;
+        int idx[ND];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) idx[a] = 0;
         if (q < npx) {
-          int idx[ND], t = q;
+          int t = q;
 #pragma unroll
           for (int a = ND - 1; a >= 0; --a) {
             const int w = bsz[a];
@@ -971,39 +1019,52 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
           in_i = in_mask<ND>(idx, rel_i, inv_r2, radius);
         }
         const unsigned long long bal = __ballot(in_i);
-        if (in_i) plist[filled + __popcll(bal & ((1ull << lane) - 1ull))] = pk;
+        if (in_i) {
+          // the pixel's value goes with it: read (and, with a lowpass, filtered) once per round
+          double pix;
+          if constexpr (LP) pix = lowpass_pixel<ND>(frame, k.frame_dtype, fshape, origin, wshape, idx, k.lp_w, k.lp_half, k.prob.threshold);
+          else {
+            const size_t offp = ND == 3
+                ? ((size_t)(idx[0] + origin[0]) * fshape[1] + (idx[1] + origin[1])) * fshape[ND - 1] + (idx[ND - 1] + origin[ND - 1])
+                : (size_t)(idx[0] + origin[0]) * fshape[ND - 1] + (idx[ND - 1] + origin[ND - 1]);
+            pix = load_pixel(frame, k.frame_dtype, offp);
+          }
+          const int at = filled + __popcll(bal & ((1ull << lane) - 1ull));
+          plist[at] = pk;
+          pvals[at] = pix;
+        }
         filled += __popcll(bal);
       }
       if (lane == 0) pix_cnt[i] = filled;
-      // ... and the pixels it shares with every neighbour j > i (out of its own list)
+      // ... and the pixels it shares with every neighbour (out of its own list: position there
+      // and packed coordinates, ascending)
       {
         const int cnt = nbcnt[i];
-        int* pool = pair_pool + (size_t)i * W.cap;
+        int2* pool = pair_pool + (size_t)i * (2 * W.cap);
         int used = 0;
         for (int s2 = 0; s2 < cnt; ++s2) {
           const int j = nbidx[(size_t)i * LARGE_MAXNB + s2];
           int got = 0;
-          if (j > i) {
-            double rel_j[ND];
+          double rel_j[ND];
 #pragma unroll
-            for (int a = 0; a < ND; ++a) rel_j[a] = mco[j * 3 + a] - (double)origin[a];
-            for (int base = 0; base < filled && got >= 0; base += WAVE) {
-              const int q = base + lane;
-              bool both = false;
-              int pk = 0;
-              if (q < filled) {
-                pk = plist[q];
-                int idx[ND];
+          for (int a = 0; a < ND; ++a) rel_j[a] = mco[j * 3 + a] - (double)origin[a];
+          for (int base = 0; base < filled && got >= 0; base += WAVE) {
+            const int q = base + lane;
+            bool both = false;
+            int pk = 0;
+            if (q < filled) {
+              pk = plist[q];
+              int idx[ND];
 #pragma unroll
-                for (int a = 0; a < ND; ++a) idx[a] = blo[a] + ((pk >> (10 * (ND - 1 - a))) & 1023);
-                both = in_mask<ND>(idx, rel_j, inv_r2, radius);
-              }
-              const unsigned long long bal = __ballot(both);
-              const int nb2 = __popcll(bal);
-              if (used + got + nb2 > (int)W.cap) { got = -1; break; }   // (the pool is full: the pass walks the box)
-              if (both) pool[used + got + __popcll(bal & ((1ull << lane) - 1ull))] = pk;
-              got += nb2;
+              for (int a = 0; a < ND; ++a) idx[a] = blo[a] + ((pk >> (10 * (ND - 1 - a))) & 1023);
+              both = in_mask<ND>(idx, rel_j, inv_r2, radius);
+              if (pvals[q] != pvals[q]) pk |= 1 << 30;   // (PK_NAN: a NaN pixel of the image)
             }
+            const unsigned long long bal = __ballot(both);
+            const int nb2 = __popcll(bal);
+            if (used + got + nb2 > 2 * (int)W.cap) { got = -1; break; }   // (the pool is full: the passes test the mask)
+            if (both) pool[used + got + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(q, pk);
+            got += nb2;
           }
           if (lane == 0) { pair_off[(size_t)i * LARGE_MAXNB + s2] = used; pair_cnt[(size_t)i * LARGE_MAXNB + s2] = got; }
           used += got > 0 ? got : 0;

@@ -31,8 +31,11 @@ if hasattr(eng._lib, 'ctr_debug_large_counters') and eng._lib.ctr_debug_large_co
         ns, ni, ncap = dbg[8 + 4 * kq], dbg[9 + 4 * kq], dbg[10 + 4 * kq]
         print('  %-38s %6d solves, %8d CG iterations (%.1f per solve), %d at the iteration cap' % (name, ns, ni, ni / max(ns, 1), ncap))
 if dbg[27]:
-    print('  per feature tile of the leader\'s wave 0 (%d tiles; shader-clock ticks): box test, index, mask, pixel %.0f; covering features %.0f; rows -> LDS, 16 MFMA %.0f' % (
+    print('  per feature tile of the leader\'s wave 0 (%d tiles; shader-clock ticks): neighbour visits (per tile of the feature) %.0f; own model %.0f; rows -> LDS, 16 MFMA %.0f' % (
         dbg[27], dbg[24] / dbg[27], dbg[25] / dbg[27], dbg[26] / dbg[27]))
+if dbg[29]:
+    print('  neighbour visits of wave 0: %d with a block (j > i): %.0f ticks each, of which MFMA %.0f, + flush %.0f; %d without: %.0f each' % (
+        dbg[29], dbg[28] / dbg[29], dbg[15] / dbg[29], dbg[11] / dbg[29], dbg[31], dbg[30] / max(dbg[31], 1)))
 print('status counts', np.bincount(b.status), 'rounds', b.n_rounds[:8], 'iters', b.n_iter[:8])
 out = np.empty_like(b.params_out); out[prep.order] = b.params_out
 ok = np.empty(len(out), bool); ok[prep.order] = np.repeat(b.status == 0, n_per)
