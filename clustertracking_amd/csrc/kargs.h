@@ -59,7 +59,8 @@ struct KernelInfo {
 // ---- workspace of one large cluster (large_kernel.h), in doubles ---------------------------
 constexpr int LARGE_MAXNB = 48;   // neighbours (features with overlapping mask ellipsoids) per feature
 constexpr int LARGE_AGG = 4;      // features per aggregate of the preconditioner
-constexpr int LARGE_AGG_STRIDE = 512;   // >= (4 * 7) (4 * 7 + 1) / 2 = 406 packed entries
+constexpr int LARGE_AGG_TRI = 416;      // >= (4 * 7) (4 * 7 + 1) / 2 = 406 packed entries of the factor
+constexpr int LARGE_AGG_STRIDE = 1280;  // ... + (4 * 7)^2 = 784 of the explicit inverse behind it
 
 struct LargeWs {
   long long nvp, nvp_i;   // variables / features rounded up to a multiple of 8

@@ -1401,30 +1401,68 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
           if (!okc) notpd = true;
         }
         if (wg_any(notpd, red, lane, wave)) continue;
+        // ... and their explicit inverses behind the factors (one thread per column; a symmetric
+        // positive definite preconditioner needs no more accuracy than that): applying the factors is a
+        // chain of ~dim^2 dependent loads for ONE thread per aggregate in every CG iteration, the
+        // inverse is NPF rows of dim products for the thread of every member
+        for (int e = tid; e < n_multi * (LARGE_AGG * MAXPF); e += LT) {
+          const int m2 = e / (LARGE_AGG * MAXPF), c = e - m2 * (LARGE_AGG * MAXPF);
+          int msz = 0;
+#pragma unroll
+          for (int q = 0; q < LARGE_AGG; ++q) msz += agg_mem[m2 * LARGE_AGG + q] >= 0 ? 1 : 0;
+          const int dim = msz * NPF;
+          if (c >= dim) continue;
+          const double* Lp = pre2 + (size_t)m2 * LARGE_AGG_STRIDE;
+          double* xc = pre2 + (size_t)m2 * LARGE_AGG_STRIDE + LARGE_AGG_TRI + (size_t)c * dim;   // column c = row c
+          for (int r = 0; r < c; ++r) xc[r] = 0.;
+          for (int r = c; r < dim; ++r) {
+            double sacc = r == c ? 1. : 0.;
+            for (int q = c; q < r; ++q) sacc -= Lp[r * (r + 1) / 2 + q] * xc[q];
+            xc[r] = sacc * Lp[r * (r + 1) / 2 + r];
+          }
+          for (int r = dim - 1; r >= 0; --r) {
+            double sacc = xc[r];
+            for (int q = r + 1; q < dim; ++q) sacc -= Lp[q * (q + 1) / 2 + r] * xc[q];
+            xc[r] = sacc * Lp[r * (r + 1) / 2 + r];
+          }
+        }
+        if (n_multi > 0) __syncthreads();
         // z = P^-1 r on this thread's features (and, thread 0, the shared block); returns r.z
         auto precond = [&](const double* rr, double* zz) -> double {
           double acc2 = 0.;
-          for (int m2 = tid; m2 < n_multi; m2 += LT) {
-            const double* Lp = pre2 + (size_t)m2 * LARGE_AGG_STRIDE;
-            int mem[LARGE_AGG], msz = 0;
-#pragma unroll
-            for (int q = 0; q < LARGE_AGG; ++q) { mem[q] = agg_mem[m2 * LARGE_AGG + q]; msz += mem[q] >= 0 ? 1 : 0; }
-            const int dim = msz * NPF;
-            auto at = [&](int ra) { const int fa = ra / NPF; return NS + mem[fa] * NPF + (ra - fa * NPF); };
-            for (int ra = 0; ra < dim; ++ra) {
-              double sacc = rr[at(ra)];
-              for (int q = 0; q < ra; ++q) sacc -= Lp[ra * (ra + 1) / 2 + q] * zz[at(q)];
-              zz[at(ra)] = sacc * Lp[ra * (ra + 1) / 2 + ra];
-            }
-            for (int ra = dim - 1; ra >= 0; --ra) {
-              double sacc = zz[at(ra)];
-              for (int q = ra + 1; q < dim; ++q) sacc -= Lp[q * (q + 1) / 2 + ra] * zz[at(q)];
-              zz[at(ra)] = sacc * Lp[ra * (ra + 1) / 2 + ra];
-            }
-            for (int ra = 0; ra < dim; ++ra) acc2 += rr[at(ra)] * zz[at(ra)];
-          }
           for (int i = tid; i < n; i += LT) {
-            if (agg_of[i] >= 0) continue;      // (a member of an aggregate: done above)
+            const int m2 = agg_of[i];
+            if (m2 >= 0) {
+              // a member of an aggregate: its NPF rows of the aggregate's inverse
+              int mem[LARGE_AGG], msz = 0, rk = 0;
+#pragma unroll
+              for (int q = 0; q < LARGE_AGG; ++q) {
+                mem[q] = agg_mem[m2 * LARGE_AGG + q];
+                msz += mem[q] >= 0 ? 1 : 0;
+                rk = mem[q] == i ? q : rk;
+              }
+              const int dim = msz * NPF;
+              const double* Mi = pre2 + (size_t)m2 * LARGE_AGG_STRIDE + LARGE_AGG_TRI + (size_t)(rk * NPF) * dim;
+              double zl[MAXPF];
+#pragma unroll
+              for (int a = 0; a < MAXPF; ++a) zl[a] = 0.;
+#pragma unroll
+              for (int fq = 0; fq < LARGE_AGG; ++fq) {
+                if (fq >= msz) continue;
+                const int bq = NS + mem[fq] * NPF;
+                for (int aq = 0; aq < NPF; ++aq) {
+                  const double rq = rr[bq + aq];
+#pragma unroll
+                  for (int a = 0; a < MAXPF; ++a)
+                    if (a < NPF) zl[a] += Mi[a * dim + fq * NPF + aq] * rq;
+                }
+              }
+              const int b0 = NS + i * NPF;
+#pragma unroll
+              for (int a = 0; a < MAXPF; ++a)
+                if (a < NPF) { zz[b0 + a] = zl[a]; acc2 += rr[b0 + a] * zl[a]; }
+              continue;
+            }
             const double* pf = pre + (size_t)i * 32;
             const int b0 = NS + i * NPF;
             double y[MAXPF];
