@@ -46,7 +46,7 @@ struct SmemL {
   // (<= LARGE_MAXNB x LNB doubles), then the neighbours' model sums of a segment of its pixels
   static constexpr int o_nb = o_sh + 64 + 48;
   static constexpr int total = o_nb + LW * LREG;
-  static_assert(LREG >= LARGE_MAXNB * LNB + 7 * 64 + 8, "room for one tile of pixels (model sum + 6 shared columns) behind a full table");
+  static_assert(LREG >= LARGE_MAXNB * LNB + 7 * 64 + 8, "room for one tile of pixels (model sum + 6 shared columns + flags) behind a full table");
   static constexpr size_t bytes = (size_t)total * sizeof(double);
 };
 
@@ -84,7 +84,7 @@ __device__ __forceinline__ bool wg_any(bool x, double* red, int lane, int wave) 
 // passes, [3] ticks (100 MHz) in matrix-vector products, [4] in pixel passes, [5] in solves,
 // [6] / [7] wave 0 of the leader in feature tiles / pair blocks
 #ifdef CTR_STAMPS
-__device__ unsigned long long g_large_dbg[32];   // [8..]: solves and CG iterations by (model, outcome), see below
+__device__ unsigned long long g_large_dbg[48];   // [8..]: solves and CG iterations by (model, outcome), see below
 #define LDBG_ADD(slot, val) atomicAdd(&g_large_dbg[slot], (unsigned long long)(val))
 #define LDBG_NOW() __builtin_amdgcn_s_memrealtime()
 #define LDBG_CYC() __builtin_amdgcn_s_memtime()
@@ -137,8 +137,8 @@ __device__ __forceinline__ double mfma4_group(const double* rows, int step, int 
 }
 // sum of the four blocks: afterwards lane 16 i + j (and its three copies) holds entry (i, j)
 __device__ __forceinline__ double mfma4_total(double v) {
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
+  v += dpp_f64<0x128>(v);   // row_ror:8 -- lanes l and l ^ 8 of a row of 16
+  v += dpp_f64<0x124>(v);   // row_ror:4
   return v;
 }
 
@@ -309,11 +309,11 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       // Behind the table, in what is left of the wavefront's region: per pixel of a SEGMENT of
       // the feature's list the sum of the neighbours' models (and of their derivative columns of
       // the shared variables, if there are any besides the background), and one byte "this
-      // feature is the lowest that covers the pixel".  cfg 3: 1072 pixels, ~12 neighbours: one
-      // segment.
+      // feature is the lowest that covers the pixel" (one BIT per pixel).  cfg 3: 1072 pixels,
+      // one segment up to 16 neighbours.
       double* accb = reg + cnt * LNB;
-      const int SEG = (((LREG - cnt * LNB) * 8) / (8 * (1 + nsh2) + 1)) & ~63;
-      unsigned char* ownf = (unsigned char*)(accb + SEG * (1 + nsh2));
+      const int SEG = (((LREG - cnt * LNB) * 64) / (64 * (1 + nsh2) + 1)) & ~63;
+      unsigned* ownf = (unsigned*)(accb + SEG * (1 + nsh2));
       wsync();
       const unsigned long long tf0 = LDBG_NOW();
       // accumulators of the own tile: one per pair (ga <= gb) of 4-column groups
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       for (int q0 = 0; q0 < npl; q0 += SEG) {
         const int q1 = q0 + SEG < npl ? q0 + SEG : npl;
         for (int e = lane; e < SEG * (1 + nsh2); e += WAVE) accb[e] = 0.;
-        for (int e = lane; e < SEG; e += WAVE) ownf[e] = 1;
+        for (int e = lane; e < SEG / 32; e += WAVE) ownf[e] = 0xffffffffu;
         wsync();
         // ---- One visit per neighbour over the pixels it shares with feature i (the pair's list:
         // positions in i's list, ascending, and coordinates; every lane at work): its model into
@@ -385,7 +385,6 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
             } else if (ee < eend) {
               qi = ee;
               pk = plist[ee];
-              if (pvals[ee] != pvals[ee]) pk |= PK_NAN;
             }
             first = false;
             bool in = qi < q1;
@@ -413,7 +412,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
               const double gv = exp(-0.5 * ND * r2);  // fitfunc.py:112-118
               const double sig = tj[0];
               accb[qi - q0] += sig * gv;
-              if (j < i) ownf[qi - q0] = 0;
+              if (j < i) atomicAnd(&ownf[(qi - q0) >> 5], ~(1u << ((qi - q0) & 31)));
               if (nsh2 > 0 || pairblk) {
                 const double sdg = sig * (0.5 * ND) * gv;
                 d[0] = -gv;
@@ -493,10 +492,11 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
 #pragma unroll
             for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
-              for (int gj = 0; gj < 2; ++gj) {
-                const double v = __shfl(mfma4_total(accp[2 * gi + gj]), 16 * (a8 & 3) + (b8 & 3));
-                if ((a8 >> 2) == gi && (b8 >> 2) == gj && gi < GP && gj < GP) x = v;
-              }
+              for (int gj = 0; gj < 2; ++gj)
+                if (gi < GP && gj < GP) {
+                  const double v = __shfl(mfma4_total(accp[2 * gi + gj]), 16 * (a8 & 3) + (b8 & 3));
+                  if ((a8 >> 2) == gi && (b8 >> 2) == gj) x = v;
+                }
             double* oij = off + ((size_t)i * LARGE_MAXNB + s2) * 64;
             double* oji = off + ((size_t)j * LARGE_MAXNB + jr.y) * 64;
             if (q0 != 0) x += oij[a8 * 8 + b8];
@@ -552,7 +552,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
               Eown[a] = (double)ND * (dd[a] * fi[4 + a]);
             }
             if (ISO) d[1 + ND] = sdg * (qq * fi[10]);
-            const bool owner = ownf[q - q0] != 0;
+            const bool owner = ((ownf[(q - q0) >> 5] >> ((q - q0) & 31)) & 1u) != 0u;
             Pown += owner ? 1 : 0;
             if (res == res) {   // nansum (fitfunc.py:449,483): a NaN pixel counts in P only
               const double ow = owner ? 1. : 0.;
@@ -948,6 +948,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         wshape[a] = (int)(u - l);
       }
     }
+    const unsigned long long tr0 = LDBG_NOW();
     // neighbour lists: features whose mask ellipsoids (same semi-axes, the radius) overlap --
     // scaled centre distance <= 2; the masks are pixel subsets of the ellipsoids
     bool overflow = false;
@@ -980,6 +981,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         rev[(size_t)i * LARGE_MAXNB + s2] = r;
       }
     }
+    const unsigned long long tr1 = LDBG_NOW();
     // the mask pixels of every feature in this round's window, compacted: box coordinates in box
     // order, 10 bits per axis (one wavefront per feature; 41 cheap tiles for a 9 x 17 x 17 box,
     // once per round against ~25 passes over them)
@@ -998,6 +1000,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       }
       int* plist = pix_list + (size_t)i * W.cap;
       double* pvals = pix_val + (size_t)i * W.cap;
+      int* lpk = (int*)(smem + SmemL::o_nb + wave * LREG);
       int filled = 0;
       for (int base = 0; base < npx; base += WAVE) {
         const int q = base + lane;
@@ -1020,7 +1023,25 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         }
         const unsigned long long bal = __ballot(in_i);
         if (in_i) {
-          // the pixel's value goes with it: read (and, with a lowpass, filtered) once per round
+          const int at = filled + __popcll(bal & ((1ull << lane) - 1ull));
+          plist[at] = pk;
+          if (at < 2 * LREG) lpk[at] = pk;   // (a copy in LDS for the loops below)
+        }
+        filled += __popcll(bal);
+      }
+      if (lane == 0) pix_cnt[i] = filled;
+      const bool lds_list = filled <= 2 * LREG;
+      wsync();
+      // the pixels' values go with them: read (and, with a lowpass, filtered) once per round; a loop
+      // of its own over the compacted list, so that the loads of several tiles are in flight
+#pragma unroll 4
+      for (int base = 0; base < filled; base += WAVE) {
+        const int q = base + lane;
+        if (q < filled) {
+          const int pk = lds_list ? lpk[q] : plist[q];
+          int idx[ND];
+#pragma unroll
+          for (int a = 0; a < ND; ++a) idx[a] = blo[a] + ((pk >> (10 * (ND - 1 - a))) & 1023);
           double pix;
           if constexpr (LP) pix = lowpass_pixel<ND>(frame, k.frame_dtype, fshape, origin, wshape, idx, k.lp_w, k.lp_half, k.prob.threshold);
           else {
@@ -1029,13 +1050,14 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
                 : (size_t)(idx[0] + origin[0]) * fshape[ND - 1] + (idx[ND - 1] + origin[ND - 1]);
             pix = load_pixel(frame, k.frame_dtype, offp);
           }
-          const int at = filled + __popcll(bal & ((1ull << lane) - 1ull));
-          plist[at] = pk;
-          pvals[at] = pix;
+          pvals[q] = pix;
+          if (pix != pix) {   // (PK_NAN: a NaN pixel of the image; the pair lists inherit the flag)
+            plist[q] = pk | (1 << 30);
+            if (lds_list) lpk[q] = pk | (1 << 30);
+          }
         }
-        filled += __popcll(bal);
       }
-      if (lane == 0) pix_cnt[i] = filled;
+      wsync();
       // ... and the pixels it shares with every neighbour (out of its own list: position there
       // and packed coordinates, ascending)
       {
@@ -1051,14 +1073,28 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
           for (int base = 0; base < filled && got >= 0; base += WAVE) {
             const int q = base + lane;
             bool both = false;
-            int pk = 0;
+            int pk = q < filled ? (lds_list ? lpk[q] : plist[q]) : 0;
+            {
+              // can the box of j touch these 64 list pixels at all?  (box order: the slowest axis
+              // runs from the first lane's to the last lane's value; an axis below one that changes
+              // spans its whole range)
+              const int last = base + WAVE - 1 < filled ? WAVE - 1 : filled - 1 - base;
+              bool same = true, hit = true;
+#pragma unroll
+              for (int a = 0; a < ND; ++a) {
+                const int c0 = __builtin_amdgcn_readfirstlane((pk >> (10 * (ND - 1 - a))) & 1023);
+                const int c1 = __builtin_amdgcn_readlane((pk >> (10 * (ND - 1 - a))) & 1023, last);
+                const int lo_a = blo[a] + (same ? c0 : 0), hi_a = blo[a] + (same ? c1 : bsz[a] - 1);
+                hit = hit && ((double)hi_a >= rel_j[a] - (double)radius[a]) && ((double)lo_a <= rel_j[a] + (double)radius[a]);
+                same = same && c0 == c1;
+              }
+              if (!hit) continue;
+            }
             if (q < filled) {
-              pk = plist[q];
               int idx[ND];
 #pragma unroll
               for (int a = 0; a < ND; ++a) idx[a] = blo[a] + ((pk >> (10 * (ND - 1 - a))) & 1023);
               both = in_mask<ND>(idx, rel_j, inv_r2, radius);
-              if (pvals[q] != pvals[q]) pk |= 1 << 30;   // (PK_NAN: a NaN pixel of the image)
             }
             const unsigned long long bal = __ballot(both);
             const int nb2 = __popcll(bal);
@@ -1088,13 +1124,25 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
     // (three distance bands: <= 0.5, <= 1, <= 1.5 sizes), at most LARGE_AGG features per aggregate;
     // one thread, deterministic.  Measured on a 500-feature stack (numpy replica of the matrix at
     // the start vector): 137 -> 16 iterations to a relative residual of 1e-4.
-    if (tid == 0) {
-      for (int i = 0; i < n; ++i) { agg_par[i] = i; agg_sz[i] = 1; }
-      auto find = [&](int i) { while (agg_par[i] != i) { agg_par[i] = agg_par[agg_par[i]]; i = agg_par[i]; } return i; };
-      for (int band = 0; band < 3; ++band) {
-        const double lo2 = band == 0 ? -1. : (band == 1 ? 0.25 : 1.), hi2 = band == 0 ? 0.25 : (band == 1 ? 1. : 2.25);
-        for (int i = 0; i < n; ++i) {
-          const int cnt = nbcnt[i];
+    const unsigned long long tr2 = LDBG_NOW();
+    // (The candidate pairs -- closer than 1.5 sizes, few -- are found by all threads; the one thread
+    //  that unites them works on tables in LDS while they fit, n <= 1600: on the workspace its
+    //  dependent loads cost 20 ms per round for 500 features.)
+    {
+      constexpr int CMAX = 8;                      // candidates kept per feature (j > i, nearest bands first)
+      const bool in_lds = 14 * n + 8 <= 2 * LW * LREG;
+      int* ibase = in_lds ? (int*)(smem + SmemL::o_nb) : (int*)offC;
+      int* c_cnt = ibase;                          // [n]
+      int* c_lst = c_cnt + n;                      // [n][CMAX]: 4 j + band
+      int* l_par = in_lds ? c_lst + CMAX * n : agg_par;
+      int* l_sz = in_lds ? l_par + n : agg_sz;
+      int* l_of = in_lds ? l_sz + n : agg_of;
+      int* l_mem = in_lds ? l_of + n : agg_mem;    // [n / 2 + 1][LARGE_AGG]
+      for (int i = tid; i < n; i += LT) {
+        const int cnt = nbcnt[i];
+        int c = 0;
+        for (int band = 0; band < 3; ++band) {
+          const double lo2 = band == 0 ? -1. : (band == 1 ? 0.25 : 1.), hi2 = band == 0 ? 0.25 : (band == 1 ? 1. : 2.25);
           for (int s2 = 0; s2 < cnt; ++s2) {
             const int j = nbidx[(size_t)i * LARGE_MAXNB + s2];
             if (j <= i) continue;
@@ -1105,34 +1153,60 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
               q += d * d * 0.5 * (fpar[(size_t)i * FP + 4 + a] + fpar[(size_t)j * FP + 4 + a]);
             }
             if (!(q > lo2 && q <= hi2)) continue;
-            const int ri = find(i), rj = find(j);
-            if (ri != rj && agg_sz[ri] + agg_sz[rj] <= LARGE_AGG) {
-              const int lo_r = ri < rj ? ri : rj, hi_r = ri < rj ? rj : ri;
-              agg_par[hi_r] = lo_r;
-              agg_sz[lo_r] += agg_sz[hi_r];
-            }
+            if (c < CMAX) c_lst[i * CMAX + c] = 4 * j + band;
+            ++c;
           }
         }
+        c_cnt[i] = c < CMAX ? c : CMAX;
+        l_par[i] = i;
+        l_sz[i] = 1;
       }
-      int nm = 0;
-      for (int i = 0; i < n; ++i) {
-        const int r = find(i);
-        if (agg_sz[r] < 2) { agg_of[i] = -1; continue; }
-        if (r == i) {   // (the root is the lowest member: met first)
-          agg_of[i] = nm;
-          for (int q = 0; q < LARGE_AGG; ++q) agg_mem[nm * LARGE_AGG + q] = -1;
-          agg_mem[nm * LARGE_AGG] = i;
-          ++nm;
-        } else {
-          const int m2 = agg_of[r];
-          agg_of[i] = m2;
-          for (int q = 1; q < LARGE_AGG; ++q)
-            if (agg_mem[m2 * LARGE_AGG + q] < 0) { agg_mem[m2 * LARGE_AGG + q] = i; break; }
+      __syncthreads();
+      if (tid == 0) {
+        auto find = [&](int i) { while (l_par[i] != i) { l_par[i] = l_par[l_par[i]]; i = l_par[i]; } return i; };
+        for (int band = 0; band < 3; ++band)
+          for (int i = 0; i < n; ++i) {
+            const int c = c_cnt[i];
+            for (int t = 0; t < c; ++t) {
+              const int e = c_lst[i * CMAX + t];
+              if ((e & 3) != band) continue;
+              const int j = e >> 2;
+              const int ri = find(i), rj = find(j);
+              if (ri != rj && l_sz[ri] + l_sz[rj] <= LARGE_AGG) {
+                const int lo_r = ri < rj ? ri : rj, hi_r = ri < rj ? rj : ri;
+                l_par[hi_r] = lo_r;
+                l_sz[lo_r] += l_sz[hi_r];
+              }
+            }
+          }
+        int nm = 0;
+        for (int i = 0; i < n; ++i) {
+          const int r = find(i);
+          if (l_sz[r] < 2) { l_of[i] = -1; continue; }
+          if (r == i) {   // (the root is the lowest member: met first)
+            l_of[i] = nm;
+            for (int q = 0; q < LARGE_AGG; ++q) l_mem[nm * LARGE_AGG + q] = -1;
+            l_mem[nm * LARGE_AGG] = i;
+            ++nm;
+          } else {
+            const int m2 = l_of[r];
+            l_of[i] = m2;
+            for (int q = 1; q < LARGE_AGG; ++q)
+              if (l_mem[m2 * LARGE_AGG + q] < 0) { l_mem[m2 * LARGE_AGG + q] = i; break; }
+          }
         }
+        agg_nm[0] = nm;
       }
-      agg_nm[0] = nm;
+      __syncthreads();
+      if (in_lds) {
+        const int nm = agg_nm[0];
+        for (int i = tid; i < n; i += LT) agg_of[i] = l_of[i];
+        for (int e = tid; e < nm * LARGE_AGG; e += LT) agg_mem[e] = l_mem[e];
+      }
     }
     __syncthreads();
+    if (tid == 0) { LDBG_ADD(32, tr1 - tr0); LDBG_ADD(33, tr2 - tr1); LDBG_ADD(34, LDBG_NOW() - tr2); LDBG_ADD(38, 1); }
+    (void)tr0; (void)tr1; (void)tr2;
     const int n_multi = agg_nm[0];
     it = 0;
     mu = size_is_var ? 1. : 1e-3; nu = 2.; last_acc = true; gain = INFINITY;   // (oracle solve())
@@ -1175,6 +1249,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
             if (mu > 1e30) { status = CTR_STATUS_NO_CONVERGENCE; failed = true; }
           }
         }
+        const unsigned long long ta0 = LDBG_NOW();
         if (accept) {
           S = St;
           tiles_swapped = !tiles_swapped;   // the trial data are the accepted data now
@@ -1221,6 +1296,8 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
           }
           __syncthreads();
         }
+        if (tid == 0) LDBG_ADD(35, LDBG_NOW() - ta0);
+        (void)ta0;
       }
       need_eval = false;
       if (failed) break;
@@ -1234,6 +1311,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       const double* tl = tiles_swapped ? tileB : tileA;
       const double* ol = tiles_swapped ? offB : offA;
       // pack the accepted neighbour blocks for the matrix-vector products of this iteration
+      const unsigned long long tp0 = LDBG_NOW();
       {
         const int per = NPF * NPF;
         for (int i = wave; i < n; i += LW) {
@@ -1248,6 +1326,8 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         }
         __syncthreads();
       }
+      if (tid == 0) LDBG_ADD(36, LDBG_NOW() - tp0);
+      (void)tp0;
       // active set: fixed if at a bound and the gradient pushes outward
       double nfv[1] = {0.};
       for (int i = tid; i < nv; i += LT) {
@@ -1264,6 +1344,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       for (int attempt = newton_on ? 1 : 0; attempt >= 0 && !ok_step; --attempt) {
         const bool nwt = attempt == 1;
         // ---- preconditioner: Cholesky factors of the diagonal blocks (fixed rows = identity)
+        const unsigned long long tq0 = LDBG_NOW();
         bool notpd = false;
         for (int i = tid; i < n; i += LT) {
           const double* t = tl + (size_t)i * 256;
@@ -1427,6 +1508,8 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
           }
         }
         if (n_multi > 0) __syncthreads();
+        if (tid == 0) LDBG_ADD(37, LDBG_NOW() - tq0);
+        (void)tq0;
         // z = P^-1 r on this thread's features (and, thread 0, the shared block); returns r.z
         auto precond = [&](const double* rr, double* zz) -> double {
           double acc2 = 0.;

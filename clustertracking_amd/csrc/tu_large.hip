@@ -29,10 +29,10 @@ KernelInfo ctr_large_kernel(int ndim, int iso, int lp) {
 
 #ifdef CTR_STAMPS
 // diagnostic build only (make stamps), not part of include/ctrefine.h: totals since the last reset
-extern "C" int ctr_debug_large_counters(unsigned long long* out32, int reset) {
-  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_large_dbg), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+extern "C" int ctr_debug_large_counters(unsigned long long* out48, int reset) {
+  if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_large_dbg), sizeof(unsigned long long) * 48) != hipSuccess) return 1;
   if (reset) {
-    unsigned long long z[32] = {0};
+    unsigned long long z[48] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_large_dbg), z, sizeof z) != hipSuccess) return 1;
   }
   return 0;

@@ -21,7 +21,7 @@ n_per = np.diff(b.feat_offset)
 print('stacks %d features %d clusters %d largest %s: %.3f s (%.0f features/s)' % (
     stacks, len(f0), b.n_clusters, np.sort(n_per)[-3:], dt, len(f0) / dt))
 import ctypes
-dbg = (ctypes.c_ulonglong * 32)()
+dbg = (ctypes.c_ulonglong * 48)()
 if hasattr(eng._lib, 'ctr_debug_large_counters') and eng._lib.ctr_debug_large_counters(dbg, 1) == 0:
     print('large path (both runs): solves %d, CG iterations %d (%.1f per solve), pixel passes %d' % (
         dbg[0], dbg[1], dbg[1] / max(dbg[0], 1), dbg[2]))
@@ -33,6 +33,9 @@ if hasattr(eng._lib, 'ctr_debug_large_counters') and eng._lib.ctr_debug_large_co
 if dbg[27]:
     print('  per feature tile of the leader\'s wave 0 (%d tiles; shader-clock ticks): neighbour visits (per tile of the feature) %.0f; own model %.0f; rows -> LDS, 16 MFMA %.0f' % (
         dbg[27], dbg[24] / dbg[27], dbg[25] / dbg[27], dbg[26] / dbg[27]))
+if dbg[38]:
+    print('  %d rounds: neighbour lists %.3f s, pixel / pair lists %.3f s, aggregates %.3f s; accept / tabulate %.3f s, packing the blocks %.3f s, factorisations %.3f s' % (
+        dbg[38], dbg[32] * 1e-8, dbg[33] * 1e-8, dbg[34] * 1e-8, dbg[35] * 1e-8, dbg[36] * 1e-8, dbg[37] * 1e-8))
 if dbg[29]:
     print('  neighbour visits of wave 0: %d with a block (j > i): %.0f ticks each, of which MFMA %.0f, + flush %.0f; %d without: %.0f each' % (
         dbg[29], dbg[28] / dbg[29], dbg[15] / dbg[29], dbg[11] / dbg[29], dbg[31], dbg[30] / max(dbg[31], 1)))
