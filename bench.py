@@ -40,6 +40,9 @@ def parse():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                          "the N > 1 code path on a one-GPU box)")
+    ap.add_argument('--size-var', action='store_true',
+                    help="cfg3 with param_mode=dict(size='var') (SURVEY 8d names both): 7 variables "
+                         "per feature instead of 4")
     ap.add_argument('--features', type=int, default=None,
                     help="features per frame/stack (default: the workload's own)")
     ap.add_argument('--in-flight', type=int, default=10,
@@ -219,8 +222,10 @@ def main():
         frames, f0, truth, opts = workloads.cfg3(args.frames, first_seed=shard * args.frames,
                                                  n_features=nfeat)
         wl_text = ("cfg3: %d stacks/GPU of 64x128x128 uint8, %d Gaussians/stack, size (2,4,4), "
-                   "diameter (9,17,17), anisotropic Gaussian model, default param modes"
-                   % (args.frames, nfeat))
+                   "diameter (9,17,17), anisotropic Gaussian model, %s"
+                   % (args.frames, nfeat, "param_mode size='var'" if args.size_var else "default param modes"))
+        if args.size_var:
+            extra['param_mode'] = dict(size='var')
     else:
         frames, f0, truth, opts = workloads.cfg5(args.frames, first_seed=shard * args.frames)
         extra['constraints'] = cta.constraints.dimer(6., 2)
@@ -529,6 +534,20 @@ def main():
             tj = json.load(open(tf))
             traffic = tj['refine_kernels']['bytes_corrected']
             traffic_source = "committed profile (%s), not this run" % tj.get('profile', 'profiles/traffic_cfg2.json')
+        tf3 = os.path.join(ROOT, 'profiles', 'traffic_cfg3.json')
+        if args.workload == 'cfg3' and args.frames == 64 and not args.size_var and os.path.exists(tf3):
+            tj = json.load(open(tf3))     # (same: the committed FETCH_SIZE / WRITE_SIZE passes of the 64-stack step)
+            traffic = tj['refine_large_kernel']['bytes_corrected']
+            traffic_source = "committed profile (%s), not this run" % tj.get('profile', 'profiles/traffic_cfg3.json')
+        n_per_cluster = np.diff(hb.feat_offset)
+        if hb.n_clusters and int(n_per_cluster.max()) > 64:
+            kernel_names = ("refine stage: refine_large_kernel<%d,%s> (leader workgroup per cluster; %.0f %% of the features) + the "
+                            "small / block kernels for the rest" % (prep.problem.ndim, 'iso' if prep.problem.isotropic else 'aniso',
+                                                                    100. * n_per_cluster[n_per_cluster > 64].sum() / max(n_feat, 1)))
+        elif args.workload == 'cfg5':
+            kernel_names = "refine stage: refine_block_kernel<2,iso,NT,W> + its constrained instantiations (concurrent streams)"
+        else:
+            kernel_names = "refine stage: refine_small_kernel<2,1|2> + refine_block_kernel<2,iso,NT,W> (concurrent streams)"
         flops, exps, by_size = algorithmic_flops(prep.problem, hb, hb.n_iter)
         # engine vs the reference's algorithm over the WHOLE workload (all 41 033 clusters, SLSQP with
         # the default and with a converged tolerance): tools/full_parity.py on the GPU box, committed
@@ -557,7 +576,7 @@ def main():
             "failed_clusters": n_fail,
             "mean_solver_iterations": mean_iters,
             "parity_full_workload": full_parity,
-            "roofline": {"bound": "hbm", "kernel": "refine stage: refine_small_kernel<2,1|2> + refine_block_kernel<2,iso,NT,W> (concurrent streams)",
+            "roofline": {"bound": "hbm", "kernel": kernel_names,
                          "achieved": alg_bytes / rf / 1e9, "peak": peak, "unit": "GB/s",
                          "frac": alg_bytes / rf / 1e9 / peak, "traffic": traffic,
                          "traffic_source": traffic_source,

@@ -1,6 +1,6 @@
 """BASELINE cfg 3 at its stated density through the HIP engine (host-buffer call): time, statuses,
 rms vs truth; stack 0 against the stored oracle vector (tests/golden/cfg3_500_oracle.npz).
-    python tests/tools/run_cfg3.py [stacks] [features]"""
+    python tests/tools/run_cfg3.py [stacks] [features] [sizevar|default] [maxiter]     (sizevar: param_mode=dict(size='var'))"""
 import os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')
 for p in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'oracle')):
@@ -12,7 +12,9 @@ from clustertracking_amd import workloads, _lib
 stacks = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 nf = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 frames, f0, truth, opts = workloads.cfg3(stacks, 0, n_features=nf)
-prep = cta.prepare_batch(f0, cta.ArrayReader(frames), opts['diameter'])
+sizevar = len(sys.argv) > 3 and sys.argv[3] == 'sizevar'
+prep = cta.prepare_batch(f0, cta.ArrayReader(frames), opts['diameter'], param_mode=dict(size='var') if sizevar else None,
+                         **(dict(solver_maxiter=int(sys.argv[4])) if len(sys.argv) > 4 else {}))
 b = prep.batch
 eng = _lib.default_engine(0)
 eng.refine_batch(prep.problem, b)
@@ -44,7 +46,7 @@ out = np.empty_like(b.params_out); out[prep.order] = b.params_out
 ok = np.empty(len(out), bool); ok[prep.order] = np.repeat(b.status == 0, n_per)
 print('rms vs truth %.4f px over %d features' % (np.sqrt(np.mean((out[ok, 2:5] - truth[ok]) ** 2)), ok.sum()))
 gold = os.path.join(ROOT, 'tests', 'golden', 'cfg3_500_oracle.npz')
-if nf == 500 and os.path.exists(gold):
+if nf == 500 and not sizevar and os.path.exists(gold):
     z = np.load(gold)
     n0 = int(z['feat_offset'][-1])
     d = np.abs(b.params_out[:n0, 2:5] - z['params_out'][:, 2:5]).max()

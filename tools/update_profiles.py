@@ -59,7 +59,10 @@ t['profile'] = 'profiles/%s_pmc_per_launch.csv' % RND
 t['source'] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (profiles/%s_pmc_per_launch.csv), "
                "per launch; tools/profile_r3.sh" % RND)
 t['frame_max_kernel'].update(FETCH_SIZE_KB=fm_f, WRITE_SIZE_KB=fm_w, bytes_corrected=(2 * fm_f + fm_w) * 1024)
-t['refine_kernels'].update(FETCH_SIZE_KB=f, WRITE_SIZE_KB=w, bytes_corrected=(2 * f + w) * 1024)
+t['refine_kernels'].update(FETCH_SIZE_KB=f, WRITE_SIZE_KB=w, bytes_corrected=(2 * f + w) * 1024,
+                           correction="x2 applied to FETCH_SIZE: the counter reports one 64-B unit per 128-B line filled, for "
+                                      "streams and for 1-byte gathers alike (profiles/r03_fetch_calibration.json, tools/fetch_calib.hip); "
+                                      "lines are filled once per XCD that touches them, so this is a count of line fills, not a bound")
 json.dump(t, open('profiles/traffic_cfg2.json', 'w'), indent=1)
 
 # ---- SQ / GRBM counters, one batch at a time (five passes) -----------------------------------------
@@ -125,6 +128,18 @@ if glob.glob('%s/cfg3_prof/*/*kernel_stats.csv' % SRC):
                 for k, v in per.items():
                     if 'refine_' in k or 'frame_max' in k:
                         fo.write('%s,"%s",%d,%.3f\n' % (cname, k, len(v), sum(v) / len(v)))
+    # HBM traffic of the large-cluster kernel per launch (64 stacks, one batch at a time), for bench.py's cfg 3 line
+    try:
+        pf3, pw3 = per_kernel('cfg3_pmc_fetch')['FETCH_SIZE'], per_kernel('cfg3_pmc_write')['WRITE_SIZE']
+        kf = [k for k in pf3 if 'refine_large_kernel' in k][0]
+        f3, w3 = sum(pf3[kf]) / len(pf3[kf]), sum(pw3[kf]) / len(pw3[kf])
+        json.dump({"workload": "cfg3, 64 stacks of 64x128x128 uint8, 500 features per stack, one batch at a time",
+                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (profiles/%s_cfg3_pmc_per_launch.csv), per launch; tools/profile_r3.sh" % RND,
+                   "refine_large_kernel": {"FETCH_SIZE_KB": f3, "WRITE_SIZE_KB": w3, "bytes_corrected": (2 * f3 + w3) * 1024,
+                                           "correction": "x2 applied to FETCH_SIZE (one 64-B unit per 128-B line filled, profiles/r03_fetch_calibration.json)"},
+                   "profile": "profiles/%s_cfg3_pmc_per_launch.csv" % RND}, open('profiles/traffic_cfg3.json', 'w'), indent=1)
+    except (KeyError, IndexError) as e:
+        print('no cfg3 traffic:', e)
     print('cfg3 profiles written')
 # ---- what FETCH_SIZE counts (tools/fetch_calib.hip) ---------------------------------------------------
 if glob.glob('%s/fetch_calib/*/*counter_collection.csv' % SRC):
