@@ -299,6 +299,25 @@ def test_large_cluster_path_vs_oracle(engine, oracle, mode):
     assert rms < 0.05, rms
 
 
+@pytest.mark.parametrize("mode", [None, dict(signal='cluster'), dict(size='var')])
+def test_large_cluster_path_wide_masks_vs_oracle(engine, oracle, mode):
+    """The large kernel where its per-wavefront LDS region does not hold a feature's pixels at once
+    and the pool of pair lists overflows: 72 features of size 8 (diameter 51: 1963 mask pixels each,
+    ~30 neighbours sharing 20 000 pixels with a feature) -- segments of the pixel list, pair blocks
+    summed over segments, pairs walked over the own list with the mask test; with a shared signal
+    also the per-pixel sums of the neighbours' derivative columns."""
+    im, f0, truth = _grid_cluster(8, 9, 16., 5, size=8.)
+    prep = cta.prepare_batch(f0, im, 51, param_mode=mode)
+    assert prep.batch.n_clusters == 1 and prep.batch.n_features == 72
+    ref = clone_batch(prep.batch)
+    engine.refine_batch(prep.problem, prep.batch)
+    oracle.run_batch(prep.problem, ref, n_threads=1)
+    assert prep.batch.status[0] == 0 == ref.status[0]
+    assert_batches_close(prep.batch, ref, slice(2, 4), atol=1e-6)
+    rms = np.sqrt(np.mean((prep.batch.params_out[:, 2:4] - truth[prep.order]) ** 2))
+    assert rms < 0.08, rms
+
+
 def test_cfg3_at_its_stated_density(engine):
     """BASELINE cfg 3 as specified: 500 features per 64x128x128 stack percolate into ONE cluster
     of 500 features (2001 variables).  Stack 0 against the oracle's stored result
