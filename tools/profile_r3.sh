@@ -31,7 +31,7 @@ python $R/bench.py --workload cfg5 --no-cpu-baseline > $O/bench_cfg5.json 2>> $O
 echo cfg5 done
 # cfg 3 at its stated density (64 stacks of 500 features: the large-cluster kernel), ten batches in
 # flight and one; kernel stats and counters with one batch at a time (a step is seconds)
-python $R/bench.py --workload cfg3 --frames 64 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_cfg3.json 2>> $O/bench.err
+python $R/bench.py --workload cfg3 --frames 64 --steps 20 --warmup 5 > $O/bench_cfg3.json 2>> $O/bench.err
 python $R/bench.py --workload cfg3 --frames 64 --steps 4 --warmup 1 --in-flight 1 --no-cpu-baseline > $O/bench_cfg3_inflight1.json 2>> $O/bench.err
 echo cfg3 bench done
 C3="--workload cfg3 --frames 64 --steps 2 --warmup 1 --in-flight 1 --no-cpu-baseline"
