@@ -84,6 +84,7 @@ from clustertracking_amd.parallel import Inbox, open_inbox   # noqa: E402  (the 
 
 def n_vars_of(problem, n):
     """optimiser variables of a cluster of n features (fitfunc.py:207-263, groups=None)"""
+    from clustertracking_amd import _abi
     nv = 0
     for k in range(problem.n_params):
         m = problem.modes[k]
