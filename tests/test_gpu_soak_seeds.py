@@ -19,7 +19,9 @@ pytestmark = pytest.mark.gpu
 SEEDS = [300279, 300733, 303063, 304636, 305143, 305359, 305365,
          # the final build's soaks (gpurun_out/r3_soak_*.log: 12 150 + 5 925 + 4 104 + 5 898 clusters; every
          # differing cluster is a constrained fit of cost 0.02-0.22 that wanders for 50-300 iterations)
-         401359, 402708, 411174, 411337, 430763, 430892, 432582, 433968, 434721, 435356, 435783]
+         401359, 402708, 411174, 411337, 430763, 430892, 432582, 433968, 434721, 435356, 435783,
+         # after the inv_series / large-kernel work (gpurun_out/r3_soak_final_*.log: 16 037 + 12 169 clusters)
+         20059, 22661, 23138, 23638, 23713, 31972, 32840, 32883]
 EPS = (1e-13, -1e-13, 3e-13, -3e-13, 1e-12, -1e-12)
 
 
