@@ -1,6 +1,6 @@
 // Probe of the operand / result layout of v_mfma_f64_4x4x4_4b_f64 on gfx950: for every pair of
 // lanes (la, lb) A = 1 in lane la, B = 1 in lane lb, 0 elsewhere; prints which result lane is 1.
-//   hipcc --offload-arch=gfx950 -O2 tools/mfma_probe.hip -o /tmp/mfma_probe && /tmp/mfma_probe
+//   hipcc --offload-arch=gfx950 -O2 tools/mfma_probe.hip -o tools/_stamps/mfma_probe ; gpurun -- tools/_stamps/mfma_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
