@@ -15,6 +15,9 @@ frames, f0, truth, opts = workloads.cfg3(stacks, 0, n_features=nf)
 sizevar = len(sys.argv) > 3 and sys.argv[3] == 'sizevar'
 prep = cta.prepare_batch(f0, cta.ArrayReader(frames), opts['diameter'], param_mode=dict(size='var') if sizevar else None,
                          **(dict(solver_maxiter=int(sys.argv[4])) if len(sys.argv) > 4 else {}))
+if os.environ.get('CFG3_THROUGHPUT'):
+    from clustertracking_amd import _abi
+    prep.problem.flags |= _abi.FLAG_THROUGHPUT      # one workgroup per large cluster (no helpers)
 b = prep.batch
 eng = _lib.default_engine(0)
 eng.refine_batch(prep.problem, b)

@@ -33,6 +33,10 @@ echo cfg5 done
 # flight and one; kernel stats and counters with one batch at a time (a step is seconds)
 python $R/bench.py --workload cfg3 --frames 64 --steps 20 --warmup 5 > $O/bench_cfg3.json 2>> $O/bench.err
 python $R/bench.py --workload cfg3 --frames 64 --steps 4 --warmup 1 --in-flight 1 --no-cpu-baseline > $O/bench_cfg3_inflight1.json 2>> $O/bench.err
+# (the clusters of a batch last 0.1 - 3 s: with 64 stacks per batch and ten batches in flight compute units wait
+#  for the batches' stragglers; 192 stacks per batch keep them busy -- more batches in flight would do the same
+#  but oversubscribe the hardware queues)
+python $R/bench.py --workload cfg3 --frames 192 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_cfg3_192.json 2>> $O/bench.err
 echo cfg3 bench done
 C3="--workload cfg3 --frames 64 --steps 2 --warmup 1 --in-flight 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg3_prof -- python $R/bench.py $C3 > $O/cfg3_prof.log 2>&1

@@ -104,7 +104,8 @@ shutil.copy(latest('%s/prof/*/*kernel_stats.csv' % SRC), 'profiles/%s_kernel_sta
 shutil.copy(latest('%s/prof_inflight1/*/*kernel_stats.csv' % SRC), 'profiles/%s_kernel_stats_inflight1.csv' % RND)
 for fn, o in (('bench', '%s_bench.json' % RND), ('bench_inflight1', '%s_bench_inflight1.json' % RND),
               ('bench_cfg5', '%s_bench_cfg5.json' % RND), ('bench_cfg3', '%s_bench_cfg3.json' % RND),
-              ('bench_cfg3_inflight1', '%s_bench_cfg3_inflight1.json' % RND)):
+              ('bench_cfg3_inflight1', '%s_bench_cfg3_inflight1.json' % RND),
+              ('bench_cfg3_192', '%s_bench_cfg3_192stacks.json' % RND)):
     path = '%s/%s.json' % (SRC, fn)
     if not os.path.exists(path):
         continue
