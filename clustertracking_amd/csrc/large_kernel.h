@@ -344,6 +344,10 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         // tile of the next neighbour's list is fetched while this one is worked on (a visit is
         // one L2 / HBM round trip otherwise: the wavefront has one companion on its SIMD).
         const unsigned long long tc_a = LDBG_CYC();
+        int pk_n = 0, pk_n2 = 0;      // list entries of the first two own tiles: in flight during the visits
+        double px_n = 0., px_n2 = 0.;
+        if (q0 + lane < q1) { pk_n = plist[q0 + lane]; px_n = pvals[q0 + lane]; }
+        if (q0 + WAVE + lane < q1) { pk_n2 = plist[q0 + WAVE + lane]; px_n2 = pvals[q0 + WAVE + lane]; }
         int2 en_next = make_int2(0x7fffffff, 0);
         {
           const double* t0 = reg;
@@ -513,18 +517,16 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         const unsigned long long tc_b = LDBG_CYC();
         if (tid == 0 && !helper) LDBG_ADD(24, tc_b - tc_a);
         (void)tc_a; (void)tc_b;
-        // ---- the feature's own tiles of this segment (the next tile's list entries are fetched
-        // while this one is worked on)
-        int pk_n = 0;
-        double px_n = 0.;
-        if (q0 + lane < q1) { pk_n = plist[q0 + lane]; px_n = pvals[q0 + lane]; }
+        // ---- the feature's own tiles of this segment (their list entries are fetched two tiles
+        // ahead, the first two before the visits above)
         for (int base = q0; base < q1; base += WAVE) {
           const unsigned long long tc_c = LDBG_CYC();
           const int q = base + lane;
           const bool in_i = q < q1;
           const int pk = pk_n;
           const double pix = px_n;
-          if (q + WAVE < q1) { pk_n = plist[q + WAVE]; px_n = pvals[q + WAVE]; }
+          pk_n = pk_n2; px_n = px_n2;
+          if (q + 2 * WAVE < q1) { pk_n2 = plist[q + 2 * WAVE]; px_n2 = pvals[q + 2 * WAVE]; }
           int idx[ND];
 #pragma unroll
           for (int a = 0; a < ND; ++a) idx[a] = in_i ? blo[a] + ((pk >> (10 * (ND - 1 - a))) & 1023) : 0;
