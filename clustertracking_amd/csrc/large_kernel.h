@@ -14,10 +14,12 @@
 //             the "_o" columns are multiplied by [i is the lowest feature covering the pixel],
 //             so that their sums over i count every union pixel once: S, P, shared x shared
 //   off[i][s] NPF x NPF: d_i d_j^T over mask i & mask j for the s-th neighbour j of i
-// both from Jacobian rows staged in LDS and contracted with v_mfma_f64_16x16x4_f64, one
-// wavefront per feature, no atomics (bitwise reproducible).  The bounded Levenberg-Marquardt
-// iteration is that of the other kernels (oracle solve(), m = 0); the linear system is solved by
-// conjugate gradients preconditioned with the factored diagonal blocks (the oracle factors the
+// both from Jacobian rows staged in LDS and contracted with v_mfma_f64_4x4x4_4b_f64 on the live
+// 4-column groups, one wavefront per feature over the round's lists of mask pixels (one visit per
+// neighbour for its model and the pair's block, then the own tiles), no atomics (bitwise
+// reproducible).  The bounded Levenberg-Marquardt iteration is that of the other kernels (oracle
+// solve(), m = 0); the linear system is solved by conjugate gradients preconditioned with the
+// inverted diagonal blocks of aggregates of strongly coupled features (the oracle factors the
 // dense matrix: same minimiser, iteration counts may differ).
 #ifndef CTREFINE_LARGE_KERNEL_H
 #define CTREFINE_LARGE_KERNEL_H
