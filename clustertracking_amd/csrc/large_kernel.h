@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
   double* tileB = tileA + (size_t)n * 256;       // trial point
   double* offA = ws + W.o_off;
   double* offB = offA + (size_t)n * LARGE_MAXNB * 64;
-  double* offC = ws + W.o_offc;                  // accepted blocks packed NPF x NPF (matvec)
+  double* offC = ws + W.o_offc;                  // (scratch of the aggregation beyond its LDS tables)
   int* nbcnt = (int*)(ws + W.o_int);
   int* nbidx = nbcnt + W.nvp_i;
   int* rev = nbidx + (size_t)n * LARGE_MAXNB;
@@ -503,11 +503,15 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
                   const double v = __shfl(mfma4_total(accp[2 * gi + gj]), 16 * (a8 & 3) + (b8 & 3));
                   if ((a8 >> 2) == gi && (b8 >> 2) == gj) x = v;
                 }
-            double* oij = off + ((size_t)i * LARGE_MAXNB + s2) * 64;
-            double* oji = off + ((size_t)j * LARGE_MAXNB + jr.y) * 64;
-            if (q0 != 0) x += oij[a8 * 8 + b8];
-            oij[a8 * 8 + b8] = x;
-            oji[b8 * 8 + a8] = x;
+            // (stored packed, NPF x NPF contiguous doubles per block: what the matrix-vector
+            //  products of the solves read, one or two cache lines per block)
+            if (a8 < NPF && b8 < NPF) {
+              double* oij = off + ((size_t)i * LARGE_MAXNB + s2) * (NPF * NPF);
+              double* oji = off + ((size_t)j * LARGE_MAXNB + jr.y) * (NPF * NPF);
+              if (q0 != 0) x += oij[a8 * NPF + b8];
+              oij[a8 * NPF + b8] = x;
+              oji[b8 * NPF + a8] = x;
+            }
           }
           wsync();   // (the next neighbour may cover the same pixels)
           if (tid == 0 && !helper) {
@@ -857,11 +861,9 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       }
       const int cnt = nbcnt[i];
       const int* nb = nbidx + (size_t)i * LARGE_MAXNB;
-      // (the packed copy of the accepted blocks: a block is NPF x NPF contiguous doubles, one or
-      //  two cache lines, instead of NPF half-lines spread over 512 bytes -- the products of a
-      //  solve read them ~200 times, through one CU's L2 port)
-      (void)off;
-      const double* o = offC + (size_t)i * LARGE_MAXNB * NPF * NPF + a * NPF;
+      // (a block is NPF x NPF contiguous doubles, one or two cache lines -- the products of a solve
+      //  read them ~200 times, through one CU's L2 port)
+      const double* o = off + (size_t)i * LARGE_MAXNB * NPF * NPF + a * NPF;
       if (NPF == 4) {
         // four neighbours at a time, the 20 loads of a group in flight together: one block at
         // a time the product is bound by one memory round trip per neighbour (8 wavefronts x
@@ -1314,24 +1316,6 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
       ++iters;
       const double* tl = tiles_swapped ? tileB : tileA;
       const double* ol = tiles_swapped ? offB : offA;
-      // pack the accepted neighbour blocks for the matrix-vector products of this iteration
-      const unsigned long long tp0 = LDBG_NOW();
-      {
-        const int per = NPF * NPF;
-        for (int i = wave; i < n; i += LW) {
-          const int cnt = nbcnt[i];
-          const double* src = ol + (size_t)i * LARGE_MAXNB * 64;
-          double* dst = offC + (size_t)i * LARGE_MAXNB * per;
-          for (int e = lane; e < cnt * per; e += WAVE) {
-            const int s2 = e / per, r = e - s2 * per;
-            const int a = r / NPF, b = r - a * NPF;
-            dst[e] = src[s2 * 64 + a * 8 + b];
-          }
-        }
-        __syncthreads();
-      }
-      if (tid == 0) LDBG_ADD(36, LDBG_NOW() - tp0);
-      (void)tp0;
       // active set: fixed if at a bound and the gradient pushes outward
       double nfv[1] = {0.};
       for (int i = tid; i < nv; i += LT) {
@@ -1462,7 +1446,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
                   const int cnt = nbcnt[ia];
                   for (int s3 = 0; s3 < cnt; ++s3)
                     if (nbidx[(size_t)ia * LARGE_MAXNB + s3] == ib) {
-                      h = offC[((size_t)ia * LARGE_MAXNB + s3) * NPF * NPF + a * NPF + b];
+                      h = ol[((size_t)ia * LARGE_MAXNB + s3) * NPF * NPF + a * NPF + b];
                       break;
                     }
                 }
