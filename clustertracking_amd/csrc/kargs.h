@@ -89,7 +89,7 @@ __host__ __device__ inline LargeWs large_ws(int n, int npf, int ns, long long ca
   // (LARGE_AGG_STRIDE doubles each), and their tables (int32: agg_of[n], parent[n], size[n],
   // members[4 (n / 2 + 1)], n_multi)
   W.o_pre2 = o; o += (nn / 2 + 1) * LARGE_AGG_STRIDE;
-  W.o_agg = o;  o += (3 * W.nvp_i + 4 * (nn / 2 + 1) + 8 + 1) / 2 + 8;
+  W.o_agg = o;  o += (3 * W.nvp_i + 4 * (nn / 2 + 1) + 8 + 16 * (nn / 2 + 1) + 1) / 2 + 8;   // (+ [n_multi][4][4] neighbour slots)
   // the mask pixels of every feature, compacted (int32: box coordinates, 10 bits per axis), rebuilt
   // every re-window round: [n] counts, then n lists of `cap` entries; their values as doubles
   W.cap = (cap + 63) & ~63LL;

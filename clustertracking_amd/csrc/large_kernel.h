@@ -202,6 +202,7 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
   int* agg_sz = agg_par + W.nvp_i;
   int* agg_mem = agg_sz + W.nvp_i;             // [n_multi][LARGE_AGG] members (-1 beyond the size)
   int* agg_nm = agg_mem + LARGE_AGG * (n / 2 + 1);   // [0] number of multi-feature aggregates
+  int* agg_slot = agg_nm + 8;                  // [n_multi][4][4]: member b's place in member a's neighbour list, -1: none
 
   // the exact second-order terms need signal and positions as per-feature variables
   bool newton_on = L.slot[1] >= 0 && L.per_feat[1];
@@ -1204,10 +1205,23 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
         agg_nm[0] = nm;
       }
       __syncthreads();
+      const int nm_all = agg_nm[0];
       if (in_lds) {
-        const int nm = agg_nm[0];
         for (int i = tid; i < n; i += LT) agg_of[i] = l_of[i];
-        for (int e = tid; e < nm * LARGE_AGG; e += LT) agg_mem[e] = l_mem[e];
+        for (int e = tid; e < nm_all * LARGE_AGG; e += LT) agg_mem[e] = l_mem[e];
+      }
+      // where the block between two members of an aggregate sits (members of a chain need not be
+      // neighbours): looked up once per round, not once per factorisation
+      for (int e = tid; e < nm_all * LARGE_AGG * LARGE_AGG; e += LT) {
+        const int m2 = e / (LARGE_AGG * LARGE_AGG), fa = (e / LARGE_AGG) % LARGE_AGG, fb = e % LARGE_AGG;
+        const int ia = l_mem[m2 * LARGE_AGG + fa], ib = l_mem[m2 * LARGE_AGG + fb];
+        int sl = -1;
+        if (ia >= 0 && ib >= 0 && ia != ib) {
+          const int cnt = nbcnt[ia];
+          for (int s3 = 0; s3 < cnt; ++s3)
+            if (nbidx[(size_t)ia * LARGE_MAXNB + s3] == ib) { sl = s3; break; }
+        }
+        agg_slot[e] = sl;
       }
     }
     __syncthreads();
@@ -1411,21 +1425,36 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
           }
           if (!okc) notpd = true;
         }
+        const unsigned long long tq1 = LDBG_NOW();
         // multi-feature aggregates: their diagonal blocks, the neighbour blocks between their
-        // members (packed copy of the accepted blocks), the same damping, masks and second-order
-        // entries; Cholesky in place in the workspace, reciprocal pivots on the diagonal
-        for (int m2 = tid; m2 < n_multi; m2 += LT) {
-          double* Lp = pre2 + (size_t)m2 * LARGE_AGG_STRIDE;
-          int mem[LARGE_AGG], msz = 0;
+        // members (the accepted packed blocks), the same damping, masks and second-order entries.
+        // One WAVEFRONT per aggregate, in its LDS region: the packed matrix entry by entry over the
+        // lanes, the cooperative Cholesky of the block kernel, then the explicit inverse -- lane c
+        // solves for column c -- written behind nothing: only the inverse is kept (a symmetric
+        // positive definite preconditioner needs no more accuracy than that; applying the factors
+        // was a chain of ~dim^2 dependent loads for ONE thread per aggregate in every CG iteration,
+        // factoring them in the workspace 0.23 ms of one thread per solve).
+        {
+          double* Hp = smem + SmemL::o_nb + wave * LREG;     // packed lower triangle, <= 406
+          double* dinv = Hp + LARGE_AGG_TRI;                 // <= 28
+          double* X = dinv + 32;                             // inverse, dim x dim <= 784
+          static_assert(LARGE_AGG_TRI + 32 + LARGE_AGG * MAXPF * LARGE_AGG * MAXPF <= LREG, "aggregate scratch in a wavefront's region");
+          for (int m2 = wave; m2 < n_multi; m2 += LW) {
+            int mem[LARGE_AGG], msz = 0;
 #pragma unroll
-          for (int q = 0; q < LARGE_AGG; ++q) { mem[q] = agg_mem[m2 * LARGE_AGG + q]; msz += mem[q] >= 0 ? 1 : 0; }
-          const int dim = msz * NPF;
-          for (int ra = 0; ra < dim; ++ra) {
-            const int fa = ra / NPF, a = ra - fa * NPF, ia = mem[fa], ba = NS + ia * NPF;
-            const bool free_a = fre[ba + a] != 0.;
-            for (int rb = 0; rb <= ra; ++rb) {
-              const int fb = rb / NPF, b = rb - fb * NPF, ib = mem[fb], bb = NS + ib * NPF;
-              const bool free_b = fre[bb + b] != 0.;
+            for (int q = 0; q < LARGE_AGG; ++q) { mem[q] = agg_mem[m2 * LARGE_AGG + q]; msz += mem[q] >= 0 ? 1 : 0; }
+            const int dim = msz * NPF, ne = dim * (dim + 1) / 2;
+            for (int e = lane; e < ne; e += WAVE) {
+              int ra = (int)((sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
+              while (ra * (ra + 1) / 2 > e) --ra;
+              while ((ra + 1) * (ra + 2) / 2 <= e) ++ra;
+              const int rb = e - ra * (ra + 1) / 2;
+              const int fa = ra / NPF, a = ra - fa * NPF, fb = rb / NPF, b = rb - fb * NPF;
+              int ia = 0, ib = 0;
+#pragma unroll
+              for (int q = 0; q < LARGE_AGG; ++q) { ia = q == fa ? mem[q] : ia; ib = q == fb ? mem[q] : ib; }
+              const int ba = NS + ia * NPF, bb = NS + ib * NPF;
+              const bool free_a = fre[ba + a] != 0., free_b = fre[bb + b] != 0.;
               double h = 0.;
               if (free_a && free_b) {
                 if (ia == ib) {
@@ -1442,62 +1471,42 @@ __global__ void __launch_bounds__(LT) refine_large_kernel(const KArgs k, double*
                   }
                   if (a == b) h += mu * Dm[ba + a];
                 } else {
-                  // block (ia, ib) if the two are neighbours (members of a chain need not be)
-                  const int cnt = nbcnt[ia];
-                  for (int s3 = 0; s3 < cnt; ++s3)
-                    if (nbidx[(size_t)ia * LARGE_MAXNB + s3] == ib) {
-                      h = ol[((size_t)ia * LARGE_MAXNB + s3) * NPF * NPF + a * NPF + b];
-                      break;
-                    }
+                  const int s3 = agg_slot[(m2 * LARGE_AGG + fa) * LARGE_AGG + fb];
+                  if (s3 >= 0) h = ol[((size_t)ia * LARGE_MAXNB + s3) * NPF * NPF + a * NPF + b];
                 }
               } else if (ra == rb) h = 1.;
-              Lp[ra * (ra + 1) / 2 + rb] = h;
+              Hp[e] = h;
             }
-          }
-          bool okc = true;
-          for (int j = 0; j < dim; ++j) {
-            double d = Lp[j * (j + 1) / 2 + j];
-            for (int q = 0; q < j; ++q) { const double l = Lp[j * (j + 1) / 2 + q]; d -= l * l; }
-            if (!(d > 0.) || !isfinite(d)) okc = false;
-            const double di = 1. / sqrt(d);
-            Lp[j * (j + 1) / 2 + j] = di;
-            for (int r = j + 1; r < dim; ++r) {
-              double sacc = Lp[r * (r + 1) / 2 + j];
-              for (int q = 0; q < j; ++q) sacc -= Lp[r * (r + 1) / 2 + q] * Lp[j * (j + 1) / 2 + q];
-              Lp[r * (r + 1) / 2 + j] = sacc * di;
+            wsync();
+            const bool okc = chol_factor_w(Hp, dinv, dim, lane);
+            if (!okc) { notpd = true; continue; }
+            // column c of the inverse: L L^T x = e_c (rows above c vanish in the forward part)
+            if (lane < dim) {
+              const int c = lane;
+              double* xc = X + c * dim;
+              for (int r = 0; r < c; ++r) xc[r] = 0.;
+              for (int r = c; r < dim; ++r) {
+                double sacc = r == c ? 1. : 0.;
+                for (int q = c; q < r; ++q) sacc -= Hp[tri(r) + q] * xc[q];
+                xc[r] = sacc * dinv[r];
+              }
+              for (int r = dim - 1; r >= 0; --r) {
+                double sacc = xc[r];
+                for (int q = r + 1; q < dim; ++q) sacc -= Hp[tri(q) + r] * xc[q];
+                xc[r] = sacc * dinv[r];
+              }
             }
+            wsync();
+            double* Mi = pre2 + (size_t)m2 * LARGE_AGG_STRIDE + LARGE_AGG_TRI;
+            for (int e = lane; e < dim * dim; e += WAVE) Mi[e] = X[e];
+            wsync();
           }
-          if (!okc) notpd = true;
         }
         if (wg_any(notpd, red, lane, wave)) continue;
-        // ... and their explicit inverses behind the factors (one thread per column; a symmetric
-        // positive definite preconditioner needs no more accuracy than that): applying the factors is a
-        // chain of ~dim^2 dependent loads for ONE thread per aggregate in every CG iteration, the
-        // inverse is NPF rows of dim products for the thread of every member
-        for (int e = tid; e < n_multi * (LARGE_AGG * MAXPF); e += LT) {
-          const int m2 = e / (LARGE_AGG * MAXPF), c = e - m2 * (LARGE_AGG * MAXPF);
-          int msz = 0;
-#pragma unroll
-          for (int q = 0; q < LARGE_AGG; ++q) msz += agg_mem[m2 * LARGE_AGG + q] >= 0 ? 1 : 0;
-          const int dim = msz * NPF;
-          if (c >= dim) continue;
-          const double* Lp = pre2 + (size_t)m2 * LARGE_AGG_STRIDE;
-          double* xc = pre2 + (size_t)m2 * LARGE_AGG_STRIDE + LARGE_AGG_TRI + (size_t)c * dim;   // column c = row c
-          for (int r = 0; r < c; ++r) xc[r] = 0.;
-          for (int r = c; r < dim; ++r) {
-            double sacc = r == c ? 1. : 0.;
-            for (int q = c; q < r; ++q) sacc -= Lp[r * (r + 1) / 2 + q] * xc[q];
-            xc[r] = sacc * Lp[r * (r + 1) / 2 + r];
-          }
-          for (int r = dim - 1; r >= 0; --r) {
-            double sacc = xc[r];
-            for (int q = r + 1; q < dim; ++q) sacc -= Lp[q * (q + 1) / 2 + r] * xc[q];
-            xc[r] = sacc * Lp[r * (r + 1) / 2 + r];
-          }
-        }
+        const unsigned long long tq2 = LDBG_NOW();
         if (n_multi > 0) __syncthreads();
-        if (tid == 0) LDBG_ADD(37, LDBG_NOW() - tq0);
-        (void)tq0;
+        if (tid == 0) { LDBG_ADD(37, LDBG_NOW() - tq0); LDBG_ADD(39, tq1 - tq0); LDBG_ADD(40, tq2 - tq1); }
+        (void)tq0; (void)tq1; (void)tq2;
         // z = P^-1 r on this thread's features (and, thread 0, the shared block); returns r.z
         auto precond = [&](const double* rr, double* zz) -> double {
           double acc2 = 0.;

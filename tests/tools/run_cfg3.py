@@ -39,8 +39,8 @@ if dbg[27]:
     print('  per feature tile of the leader\'s wave 0 (%d tiles; shader-clock ticks): neighbour visits (per tile of the feature) %.0f; own model %.0f; rows -> LDS, 16 MFMA %.0f' % (
         dbg[27], dbg[24] / dbg[27], dbg[25] / dbg[27], dbg[26] / dbg[27]))
 if dbg[38]:
-    print('  %d rounds: neighbour lists %.3f s, pixel / pair lists %.3f s, aggregates %.3f s; accept / tabulate %.3f s, factorisations %.3f s' % (
-        dbg[38], dbg[32] * 1e-8, dbg[33] * 1e-8, dbg[34] * 1e-8, dbg[35] * 1e-8, dbg[37] * 1e-8))
+    print('  %d rounds: neighbour lists %.3f s, pixel / pair lists %.3f s, aggregates %.3f s; accept / tabulate %.3f s, factorisations %.3f s (feature blocks %.3f, aggregates %.3f, their inverses %.3f)' % (
+        dbg[38], dbg[32] * 1e-8, dbg[33] * 1e-8, dbg[34] * 1e-8, dbg[35] * 1e-8, dbg[37] * 1e-8, dbg[39] * 1e-8, dbg[40] * 1e-8, (dbg[37] - dbg[39] - dbg[40]) * 1e-8))
 if dbg[29]:
     print('  neighbour visits of wave 0: %d with a block (j > i): %.0f ticks each, of which MFMA %.0f, + flush %.0f; %d without: %.0f each' % (
         dbg[29], dbg[28] / dbg[29], dbg[15] / dbg[29], dbg[11] / dbg[29], dbg[31], dbg[30] / max(dbg[31], 1)))
