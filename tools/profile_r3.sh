@@ -22,7 +22,7 @@ echo fetch done
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_write.log 2>&1
 echo write done
 i=0
-for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_sq$i -- python $R/bench.py --steps 2 --warmup 1 --in-flight 1 --no-cpu-baseline > $O/pmc_sq$i.log 2>&1
   echo sq pass $i done
@@ -45,6 +45,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cfg3_pmc_fet
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/cfg3_pmc_write -- python $R/bench.py $C3 > $O/cfg3_pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/cfg3_pmc_sq1 -- python $R/bench.py $C3 > $O/cfg3_pmc_sq1.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/cfg3_pmc_sq2 -- python $R/bench.py $C3 > $O/cfg3_pmc_sq2.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/cfg3_pmc_wait -- python $R/bench.py $C3 > $O/cfg3_pmc_wait.log 2>&1
 echo cfg3 counters done
 # what FETCH_SIZE counts for the access shapes of the engine (tools/fetch_calib.hip)
 hipcc --offload-arch=gfx950 -O2 $R/tools/fetch_calib.hip -o /tmp/fetch_calib > $O/fetch_calib_build.log 2>&1

@@ -67,7 +67,9 @@ json.dump(t, open('profiles/traffic_cfg2.json', 'w'), indent=1)
 
 # ---- SQ / GRBM counters, one batch at a time (five passes) -----------------------------------------
 sq = {}
-for i in range(1, 6):
+for i in range(1, 7):
+    if not glob.glob('%s/pmc_sq%d/*/*counter_collection.csv' % (SRC, i)):
+        continue
     for cname, per in per_kernel('pmc_sq%d' % i).items():
         sq[cname] = {k: sum(v) / len(v) for k, v in per.items() if 'refine_' in k or 'frame_max_kernel' in k}
 kernels = sorted({k for per in sq.values() for k in per})
@@ -122,7 +124,7 @@ if glob.glob('%s/cfg3_prof/*/*kernel_stats.csv' % SRC):
     shutil.copy(latest('%s/cfg3_prof/*/*kernel_stats.csv' % SRC), 'profiles/%s_cfg3_kernel_stats.csv' % RND)
     with open('profiles/%s_cfg3_pmc_per_launch.csv' % RND, 'w') as fo:
         fo.write('counter,kernel,launches,mean_value\n')
-        for d in ('cfg3_pmc_fetch', 'cfg3_pmc_write', 'cfg3_pmc_sq1', 'cfg3_pmc_sq2'):
+        for d in ('cfg3_pmc_fetch', 'cfg3_pmc_write', 'cfg3_pmc_sq1', 'cfg3_pmc_sq2', 'cfg3_pmc_wait'):
             if not glob.glob('%s/%s/*/*counter_collection.csv' % (SRC, d)):
                 continue
             for cname, per in per_kernel(d).items():
